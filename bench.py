@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native HyperDB ranking path.
+
+Metric (BASELINE.json): queries/sec + p50 latency, N=10M d=384 fp16 top-100 at 1/2/4/8 MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A step is one query call of the hot path over the whole stored matrix: metric scoring of all N rows
++ top-100, results copied back to the host (what HyperDB.query() does per call).  The matrix is
+resident in HBM before the timed region (synthetic standard-normal rows, seeded per 250k-row block so
+shards are identical for every GPU count).  With N GPUs the 10M rows are row-sharded (strong
+scaling: total work fixed); each rank scans its shard, the per-shard top-100 lists are exchanged with
+ONE RCCL all-gather and merged on every rank.
+
+One JSON line is printed by rank 0.  Besides the contract fields it carries
+  roofline      -- dominant kernel (the pass over all of V) timed with HIP events on its launch
+                   stream inside the timed region; algorithmic bytes = rows * d * sizeof(elem).
+  cpu_baseline  -- the numpy restatement of the reference (oracle/), timed on this host on a bounded
+                   row prefix and scaled linearly to N (rank 0, --gpus 1 only).
+  batched       -- config 3 of BASELINE.json (Q=256 dot-product) measured in the same run.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "local-hyperdb_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 MFMA
+BLOCK_ROWS = 250_000
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--n", type=int, default=10_000_000)
+    ap.add_argument("--d", type=int, default=384)
+    ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32"])
+    ap.add_argument("--metric", default="cosine_similarity")
+    ap.add_argument("--batch-q", type=int, default=256, help="batched leg (config 3); 0 disables")
+    ap.add_argument("--batch-steps", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=200_000)
+    ap.add_argument("--pmc-traffic", type=float, default=None,
+                    help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run")
+    return ap.parse_args()
+
+
+def make_shard(n_total, d, dtype, rank, world, device):
+    """Rows [lo, hi) of the global matrix; block b is N(0,1) from torch.Generator(seed=1234+b)."""
+    nblk = (n_total + BLOCK_ROWS - 1) // BLOCK_ROWS
+    b_lo = rank * nblk // world
+    b_hi = (rank + 1) * nblk // world
+    lo, hi = b_lo * BLOCK_ROWS, min(b_hi * BLOCK_ROWS, n_total)
+    V = torch.empty((hi - lo, d), dtype=dtype, device=device)
+    for b in range(b_lo, b_hi):
+        g = torch.Generator(device=device).manual_seed(1234 + b)
+        r0 = b * BLOCK_ROWS
+        r1 = min(r0 + BLOCK_ROWS, n_total)
+        V[r0 - lo:r1 - lo] = torch.randn((r1 - r0, d), generator=g, device=device, dtype=torch.float32).to(dtype)
+    return V, lo, hi
+
+
+def make_queries(nq, d, dtype, device):
+    g = torch.Generator(device=device).manual_seed(4321)
+    return torch.randn((nq, d), generator=g, device=device, dtype=torch.float32).to(dtype)
+
+
+def cpu_baseline(args, V_dev, Q_dev):
+    """Reference op sequence (oracle.rank == hyperDB_ranking_algorithm_sort) on a row prefix."""
+    from oracle import ranking_oracle as orc
+    rows = min(args.cpu_rows, V_dev.shape[0])
+    Vh = V_dev[:rows].cpu().numpy()
+    q = Q_dev[0].cpu().numpy()
+    orc.rank(Vh[:1000], q, top_k=args.k, metric=args.metric)       # warm numpy
+    times = []
+    t_end = time.perf_counter() + 25.0
+    while len(times) < 5 and (time.perf_counter() < t_end or not times):
+        t0 = time.perf_counter()
+        orc.rank(Vh, q, top_k=args.k, metric=args.metric)
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times))
+    scale = args.n / rows
+    try:
+        from threadpoolctl import threadpool_info
+        blas_threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+    except Exception:
+        blas_threads = os.cpu_count()
+    cores = 1 if Vh.dtype == np.float16 else blas_threads   # fp16 np.dot has no BLAS kernel: single core
+    return {
+        "value": 1.0 / (t * scale), "unit": "queries/s", "cores": int(cores), "kind": "port",
+        "sample": f"oracle.rank ({args.metric}, top-{args.k}) on the first {rows} rows, median of {len(times)} "
+                  f"queries = {t:.3f} s, scaled x{scale:.0f} to N={args.n}; host has {os.cpu_count()} cpus, "
+                  f"BLAS threads {blas_threads}",
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    from hyperdb._native import GpuIndex, METRIC_IDS
+    from hyperdb.sharded import ShardedIndex
+
+    tdtype = torch.float16 if args.dtype == "fp16" else torch.float32
+    elem = 2 if args.dtype == "fp16" else 4
+    V, lo, hi = make_shard(args.n, args.d, tdtype, rank, world, device)
+    local = GpuIndex(V, device=device, row_base=lo)
+    sharded = ShardedIndex(local, n_total=args.n, group=(dist.group.WORLD if dist else None))
+    Q = make_queries(max(args.steps + args.warmup, 1), args.d, tdtype, device)
+    mid = METRIC_IDS[args.metric]
+    torch.cuda.synchronize()
+
+    def barrier():
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---------------- single-query leg: the headline metric --------------------------------------
+    for i in range(args.warmup):
+        sharded.query(Q[i:i + 1], args.k, mid)
+    local.set_option("profile", 1)
+    barrier()
+    lat = np.empty(args.steps)
+    t_start = time.perf_counter()
+    for i in range(args.steps):
+        t0 = time.perf_counter()
+        sharded.query(Q[args.warmup + i:args.warmup + i + 1], args.k, mid)   # ends with D2H + sync
+        lat[i] = time.perf_counter() - t0
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    scan_ns = local.stat("scan_time_ns")
+    scan_launches = local.stat("scan_launches")
+    local.set_option("profile", 0)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    qps = args.steps / elapsed
+    kern_s = scan_ns * 1e-9 / max(scan_launches, 1)
+    alg_bytes = (hi - lo) * args.d * elem                    # per launch of the dominant kernel, per GPU
+    achieved = alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
+
+    # ---------------- batched leg: config 3 (Q=256 dot product) ----------------------------------
+    batched = None
+    if args.batch_q > 0:
+        bq = args.batch_q
+        QB = make_queries(bq, args.d, tdtype, device)
+        bmid = METRIC_IDS["dot_product"]
+        for _ in range(2):
+            sharded.query(QB, args.k, bmid)
+        local.set_option("profile", 1)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.batch_steps):
+            sharded.query(QB, args.k, bmid)
+        barrier()
+        bel = time.perf_counter() - t0
+        b_ns, b_l = local.stat("scan_time_ns"), local.stat("scan_launches")
+        local.set_option("profile", 0)
+        tb = torch.tensor([bel], dtype=torch.float64, device=device)
+        if dist:
+            dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+        bel = float(tb.item())
+        per_batch_kernel_s = b_ns * 1e-9 / args.batch_steps      # all scan launches of one batch
+        flops = 2.0 * bq * (hi - lo) * args.d
+        batched = {
+            "workload": f"N={args.n} d={args.d} {args.dtype} Q={bq} dot_product top-{args.k}",
+            "qps": bq * args.batch_steps / bel, "ms_per_batch": 1e3 * bel / args.batch_steps,
+            "scan_launches_per_batch": b_l / args.batch_steps,
+            "roofline_mfma": {"bound": "mfma", "achieved": flops / per_batch_kernel_s / 1e12 if per_batch_kernel_s else 0.0,
+                              "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": flops / per_batch_kernel_s / 1e12 / MFMA_F16_PEAK_TFLOPS if per_batch_kernel_s else 0.0},
+            "roofline_hbm": {"bound": "hbm", "achieved": alg_bytes / per_batch_kernel_s / 1e9 if per_batch_kernel_s else 0.0,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": alg_bytes / per_batch_kernel_s / 1e9 / HBM_PEAK_GBS if per_batch_kernel_s else 0.0},
+        }
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, V, Q)
+
+    if rank == 0:
+        out = {
+            "metric": "queries/sec, N=10M d=384 fp16 top-100 (single-query stream; p50 latency alongside)",
+            "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "p50_latency_ms": 1e3 * float(np.median(lat)),
+            "p99_latency_ms": 1e3 * float(np.percentile(lat, 99)),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if args.dtype == "fp32" else "f16 data, f32 accumulate", "data": "synthetic",
+            "config": {"workload": f"N={args.n} d={args.d} {args.dtype} Q=1 {args.metric} top-{args.k}, row-sharded x{world}",
+                       "rows_per_gpu": hi - lo, "exchange": "none" if world == 1 else "1 RCCL all-gather of packed top-k per query"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": args.pmc_traffic,
+                         "kernel": "hdb_scan_kernel (filter pass over all rows)", "kernel_us": kern_s * 1e6,
+                         "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": scan_launches},
+            "cpu_baseline": cpu,
+            "batched": batched,
+        }
+        print(json.dumps(out))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,145 @@
+/* hyperdb_hip.h -- C ABI of the MI355X (gfx950) brute-force ranking engine.
+ *
+ * Drop-in boundary for the hot path of AdamCodd/local-hyperDB.  The reference has no FFI
+ * layer: its boundary is the Python function table of hyperdb/ranking_algorithm.py, called
+ * from hyperdb/hyperdb.py:1556.  Every entry point below cites the reference interface it
+ * replaces; the Python side (local-hyperdb_amd/hyperdb/ranking_algorithm.py) keeps the
+ * reference's names and signatures and reaches these symbols through ctypes.
+ *
+ * Conventions
+ *   - All pointers named dev_* are device (HBM) pointers owned by the caller (PyTorch-ROCm
+ *     tensors on the Python side).  The library BORROWS them; it owns only its workspace.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls only
+ *     enqueue work; they do not synchronise unless stated.
+ *   - Return value: 0 (HDB_OK) or a negative hdb_status; the message of the last failure on
+ *     the calling thread is returned by hdb_last_error().
+ *   - One in-flight call per handle (the reference is single-threaded, hyperdb.py:1381-1388).
+ *   - Scores leave the device as float32; the Python shim widens to float64 like
+ *     ranking_algorithm.py:171.  Indices are int64 like numpy's argpartition output (:199).
+ */
+#ifndef HYPERDB_HIP_H
+#define HYPERDB_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hdb_index hdb_index;
+
+/* dtype of the stored matrix: HyperDB(fp_precision=...) accepts float16/32/64 (hyperdb.py:65-66). */
+enum hdb_dtype { HDB_F16 = 0, HDB_F32 = 1, HDB_F64 = 2 };
+
+/* metric strings of hyperDB_ranking_algorithm_sort's dispatch table (ranking_algorithm.py:155-163). */
+enum hdb_metric {
+    HDB_DOT = 0,        /* dot_product          ranking_algorithm.py:24-30   */
+    HDB_COSINE = 1,     /* cosine_similarity    ranking_algorithm.py:32-42   */
+    HDB_EUCLIDEAN = 2,  /* euclidean_metric     ranking_algorithm.py:44-52   (similarity 1/(1+dist)) */
+    HDB_HAMMING = 3,    /* hamming_distance     ranking_algorithm.py:128-147 (d - popcount(xor of x>0)) */
+    HDB_MANHATTAN = 4,  /* manhattan_distance   ranking_algorithm.py:54-61   */
+    HDB_JACCARD = 5,    /* jaccard_similarity   ranking_algorithm.py:63-75   */
+    HDB_PEARSON = 6,    /* pearson_correlation  ranking_algorithm.py:77-113  */
+    HDB_EUCLIDEAN_DIST = 7 /* euclidean_metric(get_similarity_score=False): raw distance, hdb_scores only */
+};
+
+enum hdb_status {
+    HDB_OK = 0,
+    HDB_ERR_ARG = -1,          /* bad shape / dtype / k / null pointer  -> ValueError in the shim  */
+    HDB_ERR_HIP = -2,          /* a HIP runtime call failed             -> RuntimeError            */
+    HDB_ERR_UNSUPPORTED = -3,  /* metric/dtype combination not built    -> NotImplementedError     */
+    HDB_ERR_NOMEM = -4
+};
+
+/* per-query status bits written by hdb_topk (device int32 per query) */
+enum hdb_query_status {
+    HDB_Q_OK = 0,
+    HDB_Q_UNDERFLOW = 1,  /* sampled threshold too high: fewer than k candidates passed */
+    HDB_Q_OVERFLOW = 2,   /* candidate buffer overflowed (massive ties or skewed sample) */
+    HDB_Q_NAN = 4         /* the query vector contains a NaN (ValueError of ranking_algorithm.py:150-151) */
+};
+
+/* Library/ABI version (major*100+minor). */
+int hdb_version(void);
+
+/* Message of the last error on this thread ("" if none). */
+const char* hdb_last_error(void);
+
+/* Register a resident N x d row-major matrix (C-contiguous, like HyperDB.vectors, hyperdb.py:80,:911).
+ * One pass over V builds the per-row caches that the reference recomputes on every query:
+ * 1/||v|| (get_norm_vector, ranking_algorithm.py:8-21, zero norm -> 1), ||v||^2, and the NaN
+ * flag (the np.isnan(vectors).any() of ranking_algorithm.py:150).  `row_base` is added to every
+ * returned index (global row id of local row 0 when the matrix is one shard of a larger one).
+ * Enqueues on `stream`; the index is usable on the same stream immediately. */
+int hdb_index_create(hdb_index** out, const void* dev_V, int64_t n, int32_t d, int dtype,
+                     int device, int64_t row_base, void* stream);
+
+/* Re-point an index at a (possibly grown / rewritten) matrix and rebuild the row caches;
+ * matrix lifecycle counterpart of commit_pending / remove_document (hyperdb.py:503-509,:721-728). */
+int hdb_index_update(hdb_index* ix, const void* dev_V, int64_t n, void* stream);
+
+void hdb_index_destroy(hdb_index* ix);
+
+/* 1 if the matrix contains a NaN (synchronises `stream` of the create/update call). */
+int hdb_index_has_nan(hdb_index* ix, int* out_flag);
+
+/* Additive per-row term applied before top-k: the recency_scores of ranking_algorithm.py:180-186.
+ * dev_bias: n floats or NULL to clear.  Borrowed until replaced/cleared. */
+int hdb_index_set_bias(hdb_index* ix, const float* dev_bias);
+
+/* Device-side builder of that term: dev_out[i] = recency_bias * exp(dev_ts[i] - ts_max), evaluated in
+ * float64 and stored as float32 (ranking_algorithm.py:183; ts_max = max(timestamps), which the caller
+ * already knows from the host-side timestamp list, hyperdb.py:1341-1344). */
+int hdb_recency_bias(const double* dev_ts, int64_t n, double recency_bias, double ts_max, float* dev_out,
+                     int device, void* stream);
+
+/* Optional row subset (filters / skip_doc, hyperdb.py:1119-1134,:1258-1308): dev_mask is n bytes,
+ * non-zero = row takes part; NULL clears.  Excluded rows score -inf and are never returned
+ * while at least k rows are included. */
+int hdb_index_set_row_mask(hdb_index* ix, const uint8_t* dev_mask);
+
+/* Full score vector of one query: the per-metric functions dot_product / cosine_similarity /
+ * euclidean_metric / hamming_distance (... :24,:32,:44,:128).  dev_q: d elements, float32 for
+ * F16/F32 matrices, float64 for F64 matrices.  dev_out: n floats.  The bias is NOT added. */
+int hdb_scores(hdb_index* ix, const void* dev_q, int metric, float* dev_out, void* stream);
+
+/* Top-k of nq independent queries: metric scoring + NaN->-inf + bias + argpartition/argsort of
+ * hyperDB_ranking_algorithm_sort (ranking_algorithm.py:168-204), for nq queries at once (the
+ * reference takes one query per call).  dev_Q: nq x d row-major (float32, or float64 for F64
+ * matrices).  Outputs: dev_idx [nq][k] int64 (row_base added; -1 where fewer than k rows exist),
+ * dev_score [nq][k] float32, sorted by (score descending, index ascending).
+ * dev_status [nq] int32 receives hdb_query_status bits; queries with a non-zero status must be
+ * re-run with hdb_topk_exact (the threshold estimate from the row sample failed for them). */
+int hdb_topk(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, int metric,
+             int64_t* dev_idx, float* dev_score, int32_t* dev_status, void* stream);
+
+/* Same contract, but by materialising all n scores per query and radix-selecting them:
+ * always exact, any tie pattern, any k <= HDB_MAX_K; dev_status is written as 0. */
+int hdb_topk_exact(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, int metric,
+                   int64_t* dev_idx, float* dev_score, int32_t* dev_status, void* stream);
+
+/* Merge `parts` per-shard top-k lists (the all-gathered [parts][nq][k] buffers of the row-sharded
+ * index) into the global top-k per query, same ordering rule.  Index -1 entries are ignored. */
+int hdb_merge_topk(const int64_t* dev_idx_parts, const float* dev_score_parts, int32_t parts,
+                   int32_t nq, int32_t k, int64_t* dev_idx, float* dev_score, int device, void* stream);
+
+/* Packed per-shard result record used for the exchange step (ONE RCCL all-gather per query batch):
+ *   [nq*k int64 indices][nq*k float32 scores][nq int32 status], padded to a multiple of 16 bytes.
+ * hdb_packed_bytes gives the record size; hdb_topk can write straight into such a record (pass
+ * base, base + nq*k*8, base + nq*k*12).  hdb_merge_topk_packed merges `parts` gathered records and
+ * ORs their status words per query into dev_status (may be NULL). */
+int64_t hdb_packed_bytes(int32_t nq, int32_t k);
+int hdb_merge_topk_packed(const void* dev_gathered, int32_t parts, int32_t nq, int32_t k, int64_t* dev_idx,
+                          float* dev_score, int32_t* dev_status, int device, void* stream);
+
+/* Largest k served by hdb_topk / hdb_topk_exact / hdb_merge_topk without the full-sort path. */
+#define HDB_MAX_K 2048
+
+/* Tuning knobs / introspection (bench and tests): name -> value, returns HDB_ERR_ARG if unknown. */
+int hdb_set_option(hdb_index* ix, const char* name, int64_t value);
+int hdb_get_stat(hdb_index* ix, const char* name, int64_t* value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYPERDB_HIP_H */

@@ -1,0 +1,494 @@
+// hdb_api.hip -- the C ABI of include/hyperdb_hip.h: handle, workspace and the top-k pipeline.
+//
+// Pipeline of hdb_topk for a chunk of queries (everything enqueued on the caller's stream):
+//   n <= CAP            : thr = -inf -> scan(filter) -> finalize                (every row is a candidate)
+//   otherwise           : scan(scores) over a strided row sample
+//                         -> 4 radix-histogram passes -> thr[q] = m-th largest sample score
+//                         -> scan(filter) over all rows (the only pass that touches all of V)
+//                         -> finalize (sort <= 8192 candidates per query, emit k)
+// hdb_topk_exact: scan(scores) over all rows -> 4 histogram passes -> collect (+ordered ties)
+//                 -> finalize.  Used for hamming (integer scores, massive ties), for queries whose
+//                 sampled threshold failed, and by tests as the on-device cross-check.
+#include "hdb_common.h"
+#include "../../include/hyperdb_hip.h"
+#include <string>
+#include <cstring>
+#include <cstdio>
+#include <algorithm>
+#include <vector>
+
+// launchers implemented in the kernel translation units
+extern "C" {
+int hdb_launch_scan(const ScanArgs* args, int dtype, int mode, int nq_launch, int max_blocks, void* stream);
+int hdb_launch_rownorm(const void* V, int64_t n, int d, int dtype, float* inv_norm, float* sqnorm, int* nan_flag, void* stream);
+int hdb_launch_qprep(const void* Q, int nq, int d, bool f64, float* qinv, float* qsq, int* qnan, void* stream);
+int hdb_launch_signpack(const void* V, int64_t n, int d, int dtype, int64_t npad, uint32_t* bits, void* stream);
+int hdb_launch_qsign(const void* Q, int nq, int d, bool f64, int W, uint32_t* qbits, void* stream);
+int hdb_launch_hamming(const ScanArgs* args, int mode, int nq_launch, const uint32_t* bits, int64_t npad, int W,
+                       const uint32_t* qbits, void* stream);
+int hdb_launch_hist(const float* scores, int64_t n, int64_t ld, int nq, uint32_t* hist, int pass, uint32_t k, void* stream);
+int hdb_launch_thr(const uint32_t* hist, int nq, int npass, uint32_t m, uint32_t sample_n, float* thr, uint32_t* cnt, void* stream);
+int hdb_launch_fill_thr(float* thr, uint32_t* cnt, int nq, float v, void* stream);
+int hdb_launch_collect(const float* scores, int64_t n, int64_t ld, int nq, const uint32_t* hist, uint32_t k, uint32_t* cnt,
+                       unsigned long long* cand, uint32_t cap, uint32_t* tie_info, void* stream);
+int hdb_launch_finalize(const unsigned long long* cand, const uint32_t* cnt, uint32_t cap, int nq, uint32_t k, uint32_t kk,
+                        int64_t row_base, int64_t* idx_out, float* score_out, int32_t* status, const int* qnan, void* stream);
+int hdb_launch_merge(const void* idx_base, int64_t idx_stride, const void* score_base, int64_t score_stride,
+                     const void* status_base, int64_t status_stride, int parts, int nq, uint32_t k, int64_t* idx_out,
+                     float* score_out, int32_t* status_out, void* stream);
+int hdb_launch_recency(const double* ts, int64_t n, double rb, double ts_max, float* out, void* stream);
+int hdb_mfma_supported(int dtype, int d, int metric);
+int hdb_launch_mfma_scan(const ScanArgs* args, int mode, int nq_launch, const void* q16, const float* sqnorm,
+                         const float* qsq, int max_blocks, void* stream);
+int hdb_launch_q_to_f16(const float* Q, int nq, int d, void* q16, void* stream);
+}
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(HDB_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));           \
+    } while (0)
+#define LAUNCH_TRY(expr)                                                                           \
+    do {                                                                                           \
+        int e_ = (expr);                                                                           \
+        if (e_ != 0) return fail(HDB_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString((hipError_t)e_)); \
+    } while (0)
+
+struct hdb_index {
+    const void* V = nullptr;
+    int64_t n = 0;
+    int32_t d = 0;
+    int dtype = HDB_F32;
+    int device = 0;
+    int64_t row_base = 0;
+    // per-row caches (owned)
+    float* inv_norm = nullptr;
+    float* sqnorm = nullptr;
+    int64_t cache_rows = 0;
+    int* nan_flag = nullptr;          // device int
+    hipStream_t build_stream = nullptr;
+    // hamming sign bits (owned, lazy)
+    uint32_t* bits = nullptr;
+    int64_t bits_npad = 0;
+    int W = 0;
+    bool bits_valid = false;
+    // borrowed
+    const float* bias = nullptr;
+    const uint8_t* mask = nullptr;
+    // scratch (owned)
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    // options
+    int64_t max_blocks = 2048;
+    int64_t force_exact = 0;
+    int64_t sample_target = 0;        // 0 = automatic
+    int64_t mfma_min_q = 8;
+    int64_t use_mfma = 1;
+    int64_t exact_bytes = (int64_t)1 << 30;
+    // stats of the last hdb_topk call
+    int64_t st_sample_rows = 0, st_sample_m = 0, st_path = 0, st_chunks = 0;
+    // optional HIP-event timing of the dominant kernel (the pass over all of V)
+    int64_t profile = 0;
+    std::vector<hipEvent_t> ev_pool;      // pairs: [2i] start, [2i+1] stop
+    size_t ev_used = 0;
+};
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct Bump {
+    char* base; size_t off = 0, cap;
+    Bump(char* b, size_t c) : base(b), cap(c) {}
+    template <typename T> T* take(size_t count) {
+        off = align_up(off, 256);
+        T* p = reinterpret_cast<T*>(base + off);
+        off += count * sizeof(T);
+        return p;
+    }
+};
+
+static int ensure_ws(hdb_index* ix, size_t bytes) {
+    if (bytes <= ix->ws_bytes) return HDB_OK;
+    if (ix->ws) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(ix->ws)); ix->ws = nullptr; ix->ws_bytes = 0; }
+    bytes = align_up(bytes + (bytes >> 2), 1 << 20);
+    HIP_TRY(hipMalloc((void**)&ix->ws, bytes));
+    ix->ws_bytes = bytes;
+    return HDB_OK;
+}
+
+extern "C" int hdb_version(void) { return 100; }
+extern "C" const char* hdb_last_error(void) { return g_err.c_str(); }
+
+static int build_caches(hdb_index* ix, hipStream_t st) {
+    if (ix->n > ix->cache_rows) {
+        if (ix->inv_norm) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(ix->inv_norm)); HIP_TRY(hipFree(ix->sqnorm)); }
+        const int64_t rows = ix->n + ix->n / 4 + 64;
+        HIP_TRY(hipMalloc((void**)&ix->inv_norm, rows * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&ix->sqnorm, rows * sizeof(float)));
+        ix->cache_rows = rows;
+    }
+    HIP_TRY(hipMemsetAsync(ix->nan_flag, 0, sizeof(int), st));
+    if (ix->n > 0) LAUNCH_TRY(hdb_launch_rownorm(ix->V, ix->n, ix->d, ix->dtype, ix->inv_norm, ix->sqnorm, ix->nan_flag, st));
+    ix->bits_valid = false;
+    ix->build_stream = st;
+    return HDB_OK;
+}
+
+extern "C" int hdb_index_create(hdb_index** out, const void* dev_V, int64_t n, int32_t d, int dtype, int device,
+                                int64_t row_base, void* stream) {
+    if (!out) return fail(HDB_ERR_ARG, "hdb_index_create: out is null");
+    if (n < 0 || d <= 0) return fail(HDB_ERR_ARG, "hdb_index_create: need n >= 0 and d > 0");
+    if (n > 0 && !dev_V) return fail(HDB_ERR_ARG, "hdb_index_create: matrix pointer is null");
+    if (dtype != HDB_F16 && dtype != HDB_F32 && dtype != HDB_F64) return fail(HDB_ERR_ARG, "hdb_index_create: dtype must be f16/f32/f64");
+    if (n >= ((int64_t)1 << 32) - 1) return fail(HDB_ERR_ARG, "hdb_index_create: at most 2^32-2 rows per shard");
+    if ((int64_t)d * 8 > 60 * 1024) return fail(HDB_ERR_ARG, "hdb_index_create: d too large for the query LDS tile");
+    HIP_TRY(hipSetDevice(device));
+    hdb_index* ix = new hdb_index();
+    ix->V = dev_V; ix->n = n; ix->d = d; ix->dtype = dtype; ix->device = device; ix->row_base = row_base;
+    hipError_t e = hipMalloc((void**)&ix->nan_flag, sizeof(int));
+    if (e != hipSuccess) { delete ix; return fail(HDB_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e)); }
+    int rc = build_caches(ix, (hipStream_t)stream);
+    if (rc != HDB_OK) { hdb_index_destroy(ix); return rc; }
+    *out = ix;
+    return HDB_OK;
+}
+
+extern "C" int hdb_index_update(hdb_index* ix, const void* dev_V, int64_t n, void* stream) {
+    if (!ix) return fail(HDB_ERR_ARG, "hdb_index_update: null index");
+    if (n < 0 || (n > 0 && !dev_V)) return fail(HDB_ERR_ARG, "hdb_index_update: bad matrix");
+    if (n >= ((int64_t)1 << 32) - 1) return fail(HDB_ERR_ARG, "hdb_index_update: at most 2^32-2 rows per shard");
+    HIP_TRY(hipSetDevice(ix->device));
+    ix->V = dev_V; ix->n = n;
+    ix->bias = nullptr; ix->mask = nullptr;
+    return build_caches(ix, (hipStream_t)stream);
+}
+
+extern "C" void hdb_index_destroy(hdb_index* ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    (void)hipDeviceSynchronize();
+    if (ix->inv_norm) (void)hipFree(ix->inv_norm);
+    if (ix->sqnorm) (void)hipFree(ix->sqnorm);
+    if (ix->nan_flag) (void)hipFree(ix->nan_flag);
+    if (ix->bits) (void)hipFree(ix->bits);
+    if (ix->ws) (void)hipFree(ix->ws);
+    for (hipEvent_t e : ix->ev_pool) (void)hipEventDestroy(e);
+    delete ix;
+}
+
+extern "C" int hdb_index_has_nan(hdb_index* ix, int* out_flag) {
+    if (!ix || !out_flag) return fail(HDB_ERR_ARG, "hdb_index_has_nan: null argument");
+    HIP_TRY(hipSetDevice(ix->device));
+    int h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, ix->nan_flag, sizeof(int), hipMemcpyDeviceToHost, ix->build_stream));
+    HIP_TRY(hipStreamSynchronize(ix->build_stream));
+    *out_flag = h;
+    return HDB_OK;
+}
+
+extern "C" int hdb_index_set_bias(hdb_index* ix, const float* dev_bias) {
+    if (!ix) return fail(HDB_ERR_ARG, "hdb_index_set_bias: null index");
+    ix->bias = dev_bias;
+    return HDB_OK;
+}
+
+extern "C" int hdb_index_set_row_mask(hdb_index* ix, const uint8_t* dev_mask) {
+    if (!ix) return fail(HDB_ERR_ARG, "hdb_index_set_row_mask: null index");
+    ix->mask = dev_mask;
+    return HDB_OK;
+}
+
+extern "C" int hdb_set_option(hdb_index* ix, const char* name, int64_t value) {
+    if (!ix || !name) return fail(HDB_ERR_ARG, "hdb_set_option: null argument");
+    if (!strcmp(name, "max_blocks")) ix->max_blocks = std::max<int64_t>(1, value);
+    else if (!strcmp(name, "force_exact")) ix->force_exact = value;
+    else if (!strcmp(name, "sample_target")) ix->sample_target = value;
+    else if (!strcmp(name, "mfma_min_q")) ix->mfma_min_q = value;
+    else if (!strcmp(name, "use_mfma")) ix->use_mfma = value;
+    else if (!strcmp(name, "exact_bytes")) ix->exact_bytes = std::max<int64_t>(1 << 20, value);
+    else if (!strcmp(name, "profile")) { ix->profile = value; ix->ev_used = 0; }
+    else return fail(HDB_ERR_ARG, std::string("hdb_set_option: unknown option ") + name);
+    return HDB_OK;
+}
+
+extern "C" int hdb_get_stat(hdb_index* ix, const char* name, int64_t* value) {
+    if (!ix || !name || !value) return fail(HDB_ERR_ARG, "hdb_get_stat: null argument");
+    if (!strcmp(name, "sample_rows")) *value = ix->st_sample_rows;
+    else if (!strcmp(name, "sample_m")) *value = ix->st_sample_m;
+    else if (!strcmp(name, "path")) *value = ix->st_path;
+    else if (!strcmp(name, "chunks")) *value = ix->st_chunks;
+    else if (!strcmp(name, "cand_cap")) *value = HDB_CAND_CAP;
+    else if (!strcmp(name, "n")) *value = ix->n;
+    else if (!strcmp(name, "ws_bytes")) *value = (int64_t)ix->ws_bytes;
+    else if (!strcmp(name, "scan_launches")) *value = (int64_t)(ix->ev_used / 2);
+    else if (!strcmp(name, "scan_time_ns")) {      // sum over recorded launches; synchronises on the last event
+        double total_ms = 0.0;
+        for (size_t i = 0; i + 1 < ix->ev_used; i += 2) {
+            if (hipEventSynchronize(ix->ev_pool[i + 1]) != hipSuccess) return fail(HDB_ERR_HIP, "hipEventSynchronize failed");
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, ix->ev_pool[i], ix->ev_pool[i + 1]) != hipSuccess) return fail(HDB_ERR_HIP, "hipEventElapsedTime failed");
+            total_ms += ms;
+        }
+        *value = (int64_t)(total_ms * 1.0e6);
+    }
+    else return fail(HDB_ERR_ARG, std::string("hdb_get_stat: unknown stat ") + name);
+    return HDB_OK;
+}
+
+// Bracket one launch with HIP events on the launch stream (bench.py: roofline.achieved).
+static void prof_begin(hdb_index* ix, hipStream_t st) {
+    if (!ix->profile) return;
+    if (ix->ev_used + 2 > ix->ev_pool.size()) {
+        if (ix->ev_pool.size() >= 16384) return;     // bounded
+        for (int i = 0; i < 2; ++i) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; ix->ev_pool.push_back(e); }
+    }
+    (void)hipEventRecord(ix->ev_pool[ix->ev_used], st);
+}
+static void prof_end(hdb_index* ix, hipStream_t st) {
+    if (!ix->profile || ix->ev_used + 2 > ix->ev_pool.size()) return;
+    (void)hipEventRecord(ix->ev_pool[ix->ev_used + 1], st);
+    ix->ev_used += 2;
+}
+
+static bool metric_ok(int metric) {
+    return metric == HDB_DOT || metric == HDB_COSINE || metric == HDB_EUCLIDEAN || metric == HDB_HAMMING ||
+           metric == HDB_EUCLIDEAN_DIST;
+}
+
+static int ensure_bits(hdb_index* ix, hipStream_t st) {
+    if (ix->bits_valid) return HDB_OK;
+    const int W = (ix->d + 31) / 32;
+    const int64_t npad = align_up((size_t)std::max<int64_t>(ix->n, 4), 4);
+    if (!ix->bits || ix->bits_npad < npad || ix->W != W) {
+        if (ix->bits) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(ix->bits)); ix->bits = nullptr; }
+        const int64_t cap = align_up((size_t)(npad + npad / 4), 4);
+        HIP_TRY(hipMalloc((void**)&ix->bits, (size_t)cap * W * sizeof(uint32_t)));
+        ix->bits_npad = cap; ix->W = W;
+    }
+    if (W > 512) return fail(HDB_ERR_UNSUPPORTED, "hamming: d > 16384 not supported");
+    HIP_TRY(hipMemsetAsync(ix->bits, 0, (size_t)ix->bits_npad * W * sizeof(uint32_t), st));
+    if (ix->n > 0) LAUNCH_TRY(hdb_launch_signpack(ix->V, ix->n, ix->d, ix->dtype, ix->bits_npad, ix->bits, st));
+    ix->bits_valid = true;
+    return HDB_OK;
+}
+
+static void base_args(const hdb_index* ix, ScanArgs& a, const void* Q, int metric) {
+    memset(&a, 0, sizeof(a));
+    a.V = ix->V; a.n = ix->n; a.d = ix->d; a.Q = Q; a.metric = metric;
+    a.inv_norm = ix->inv_norm; a.mask = ix->mask;
+    a.tile_stride = 1; a.ntiles = (ix->n + 15) / 16;
+    a.cap = HDB_CAND_CAP;
+}
+
+// One scan launch (VALU, hamming or MFMA flavour) for queries [a.q0, a.q0+cq).
+struct QueryBufs { const float* qinv; const float* qsq; const uint32_t* qbits; const void* q16; };
+static int run_scan(hdb_index* ix, ScanArgs& a, int mode, int cq, const QueryBufs& qb, bool mfma, hipStream_t st) {
+    a.qinv = qb.qinv;
+    if (a.metric == HDB_HAMMING) {
+        LAUNCH_TRY(hdb_launch_hamming(&a, mode, cq, ix->bits, ix->bits_npad, ix->W, qb.qbits, st));
+    } else if (mfma) {
+        LAUNCH_TRY(hdb_launch_mfma_scan(&a, mode, cq, qb.q16, ix->sqnorm, qb.qsq, (int)ix->max_blocks, st));
+    } else {
+        LAUNCH_TRY(hdb_launch_scan(&a, ix->dtype, mode, cq, (int)ix->max_blocks, st));
+    }
+    return HDB_OK;
+}
+
+extern "C" int hdb_scores(hdb_index* ix, const void* dev_q, int metric, float* dev_out, void* stream) {
+    if (!ix || !dev_q || !dev_out) return fail(HDB_ERR_ARG, "hdb_scores: null argument");
+    if (!metric_ok(metric)) return fail(HDB_ERR_UNSUPPORTED, "hdb_scores: metric not built");
+    if (ix->n == 0) return HDB_OK;
+    HIP_TRY(hipSetDevice(ix->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int W = (ix->d + 31) / 32;
+    int rc = ensure_ws(ix, 4096 + (size_t)W * 4 + 1024);
+    if (rc) return rc;
+    Bump b(ix->ws, ix->ws_bytes);
+    float* qinv = b.take<float>(1); float* qsq = b.take<float>(1); int* qnan = b.take<int>(1);
+    uint32_t* qbits = b.take<uint32_t>(W);
+    LAUNCH_TRY(hdb_launch_qprep(dev_q, 1, ix->d, ix->dtype == HDB_F64, qinv, qsq, qnan, st));
+    if (metric == HDB_HAMMING) {
+        rc = ensure_bits(ix, st); if (rc) return rc;
+        LAUNCH_TRY(hdb_launch_qsign(dev_q, 1, ix->d, ix->dtype == HDB_F64, W, qbits, st));
+    }
+    ScanArgs a; base_args(ix, a, dev_q, metric);
+    a.mask = nullptr;                   // per-metric functions score every row, no bias (reference :24-147)
+    a.scores = dev_out; a.ld = ix->n;
+    QueryBufs qb{qinv, qsq, qbits, nullptr};
+    return run_scan(ix, a, 0, 1, qb, false, st);
+}
+
+static void sample_plan(const hdb_index* ix, uint32_t kk, int64_t& tiles, int64_t& stride, uint32_t& m) {
+    int64_t T = ix->sample_target > 0 ? ix->sample_target : (kk <= 128 ? 2048 : 4096);
+    m = kk <= 128 ? 16u : (kk <= 512 ? 64u : 256u);
+    int64_t rows = (int64_t)((double)m * (double)ix->n / (double)T);
+    rows = std::max<int64_t>(rows, 16 * (int64_t)m);         // at least 16 m sample rows
+    tiles = (rows + 15) / 16;
+    const int64_t all_tiles = ix->n / 16;                    // full tiles only: sample rows always exist
+    tiles = std::min(tiles, all_tiles);
+    stride = std::max<int64_t>(1, all_tiles / std::max<int64_t>(tiles, 1));
+}
+
+static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, int metric, int64_t* dev_idx,
+                     float* dev_score, int32_t* dev_status, void* stream, bool exact) {
+    if (!ix || !dev_idx || !dev_score) return fail(HDB_ERR_ARG, "hdb_topk: null argument");
+    if (nq < 0 || k < 0) return fail(HDB_ERR_ARG, "hdb_topk: nq and k must be >= 0");
+    if (nq == 0 || k == 0) return HDB_OK;
+    if (!dev_Q) return fail(HDB_ERR_ARG, "hdb_topk: query pointer is null");
+    if (k > HDB_MAX_K && ix->n > HDB_CAND_CAP) return fail(HDB_ERR_UNSUPPORTED, "hdb_topk: k > HDB_MAX_K needs the full-sort path");
+    if (metric == HDB_EUCLIDEAN_DIST || !metric_ok(metric)) return fail(HDB_ERR_UNSUPPORTED, "hdb_topk: metric not built");
+    HIP_TRY(hipSetDevice(ix->device));
+    hipStream_t st = (hipStream_t)stream;
+    const bool f64 = ix->dtype == HDB_F64;
+    const int64_t n = ix->n;
+    const uint32_t kk = (uint32_t)std::min<int64_t>(k, n);
+    const int W = (ix->d + 31) / 32;
+    if (n == 0) {   // nothing stored: all -1 / -inf
+        HIP_TRY(hipMemsetAsync(dev_idx, 0xFF, (size_t)nq * k * sizeof(int64_t), st));
+        HIP_TRY(hipMemsetAsync(dev_score, 0xFF, (size_t)nq * k * sizeof(float), st));   // NaN pattern; no rows exist
+        if (dev_status) HIP_TRY(hipMemsetAsync(dev_status, 0, (size_t)nq * sizeof(int32_t), st));
+        return HDB_OK;
+    }
+    if ((size_t)std::min<int64_t>(k, HDB_CAND_CAP) > HDB_CAND_CAP) return fail(HDB_ERR_ARG, "hdb_topk: k too large");
+
+    const bool small = n <= HDB_CAND_CAP;
+    const bool is_ham = metric == HDB_HAMMING;
+    if (is_ham && !small) exact = true;                      // integer scores: massive ties by construction
+    if (ix->force_exact && !small) exact = true;
+    const bool mfma_ok = ix->use_mfma && !is_ham && hdb_mfma_supported(ix->dtype, ix->d, metric);
+
+    // ---- plan the chunking --------------------------------------------------------------------
+    int64_t s_tiles = 0, s_stride = 1; uint32_t m = 0;
+    if (!small && !exact) sample_plan(ix, kk, s_tiles, s_stride, m);
+    const int64_t s_rows = s_tiles * 16;
+    const int64_t ld_s = align_up((size_t)std::max<int64_t>(s_rows, 4), 4);
+    const int64_t ld_n = align_up((size_t)n, 4);
+    int cq_max = 256;
+    if (exact && !small) cq_max = (int)std::max<int64_t>(1, std::min<int64_t>(256, ix->exact_bytes / (ld_n * 4)));
+    cq_max = std::min(cq_max, (int)nq);
+
+    size_t need = 0;
+    need += 3 * align_up((size_t)nq * 4, 256) + 1024;                        // qinv, qsq, qnan
+    need += align_up((size_t)nq * W * 4, 256);                               // qbits
+    need += align_up((size_t)nq * ix->d * 2, 256);                           // fp16 queries (MFMA)
+    need += 2 * align_up((size_t)cq_max * 4, 256);                           // thr, cnt
+    need += align_up((size_t)cq_max * 4 * HDB_RADIX_BINS * 4, 256);          // hist
+    need += align_up((size_t)cq_max * 16, 256);                              // tie_info
+    need += align_up((size_t)cq_max * HDB_CAND_CAP * 8, 256);                // cand
+    need += align_up((size_t)cq_max * (exact && !small ? ld_n : ld_s) * 4, 256) + 4096;
+    int rc = ensure_ws(ix, need);
+    if (rc) return rc;
+    Bump b(ix->ws, ix->ws_bytes);
+    float* qinv = b.take<float>(nq); float* qsq = b.take<float>(nq); int* qnan = b.take<int>(nq);
+    uint32_t* qbits = b.take<uint32_t>((size_t)nq * W);
+    void* q16 = b.take<uint16_t>((size_t)nq * ix->d);
+    float* thr = b.take<float>(cq_max); uint32_t* cnt = b.take<uint32_t>(cq_max);
+    uint32_t* hist = b.take<uint32_t>((size_t)cq_max * 4 * HDB_RADIX_BINS);
+    uint32_t* tie_info = b.take<uint32_t>((size_t)cq_max * 4);
+    unsigned long long* cand = b.take<unsigned long long>((size_t)cq_max * HDB_CAND_CAP);
+    float* sbuf = b.take<float>((size_t)cq_max * (exact && !small ? ld_n : ld_s));
+
+    LAUNCH_TRY(hdb_launch_qprep(dev_Q, nq, ix->d, f64, qinv, qsq, qnan, st));
+    if (is_ham) {
+        rc = ensure_bits(ix, st); if (rc) return rc;
+        LAUNCH_TRY(hdb_launch_qsign(dev_Q, nq, ix->d, f64, W, qbits, st));
+    }
+    bool q16_ready = false;
+    ix->st_sample_rows = s_rows; ix->st_sample_m = m; ix->st_chunks = 0;
+    ix->st_path = small ? 0 : (exact ? 2 : 1);
+
+    for (int q0 = 0; q0 < nq; q0 += cq_max) {
+        const int cq = std::min(cq_max, nq - q0);
+        ix->st_chunks++;
+        const bool mfma = mfma_ok && cq >= ix->mfma_min_q;
+        if (mfma && !q16_ready) { LAUNCH_TRY(hdb_launch_q_to_f16((const float*)dev_Q, nq, ix->d, q16, st)); q16_ready = true; }
+        QueryBufs qb{qinv, qsq, qbits, q16};
+        ScanArgs a; base_args(ix, a, dev_Q, metric);
+        a.q0 = q0; a.bias = ix->bias;
+        a.thr = thr; a.cnt = cnt; a.cand = cand;
+
+        if (small) {
+            LAUNCH_TRY(hdb_launch_fill_thr(thr, cnt, cq, -INFINITY, st));
+            rc = run_scan(ix, a, 1, cq, qb, mfma, st); if (rc) return rc;
+        } else if (!exact) {
+            // 1) strided row sample -> sample scores
+            ScanArgs s = a;
+            s.ntiles = s_tiles; s.tile_stride = s_stride; s.scores = sbuf; s.ld = ld_s;
+            rc = run_scan(ix, s, 0, cq, qb, mfma, st); if (rc) return rc;
+            // 2) m-th largest sample score per query
+            HIP_TRY(hipMemsetAsync(hist, 0, (size_t)cq * 4 * HDB_RADIX_BINS * 4, st));
+            for (int p = 0; p < 4; ++p) LAUNCH_TRY(hdb_launch_hist(sbuf, s_rows, ld_s, cq, hist, p, m, st));
+            LAUNCH_TRY(hdb_launch_thr(hist, cq, 4, m, (uint32_t)s_rows, thr, cnt, st));
+            // 3) the pass over all of V
+            prof_begin(ix, st);
+            rc = run_scan(ix, a, 1, cq, qb, mfma, st); if (rc) return rc;
+            prof_end(ix, st);
+        } else {
+            ScanArgs s = a;
+            s.scores = sbuf; s.ld = ld_n;
+            prof_begin(ix, st);
+            rc = run_scan(ix, s, 0, cq, qb, mfma, st); if (rc) return rc;
+            prof_end(ix, st);
+            HIP_TRY(hipMemsetAsync(hist, 0, (size_t)cq * 4 * HDB_RADIX_BINS * 4, st));
+            HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)cq * 4, st));
+            for (int p = 0; p < 4; ++p) LAUNCH_TRY(hdb_launch_hist(sbuf, n, ld_n, cq, hist, p, kk, st));
+            LAUNCH_TRY(hdb_launch_collect(sbuf, n, ld_n, cq, hist, kk, cnt, cand, HDB_CAND_CAP, tie_info, st));
+        }
+        LAUNCH_TRY(hdb_launch_finalize(cand, cnt, HDB_CAND_CAP, cq, (uint32_t)k, kk, ix->row_base,
+                                       dev_idx + (int64_t)q0 * k, dev_score + (int64_t)q0 * k,
+                                       dev_status ? dev_status + q0 : nullptr, qnan + q0, st));
+    }
+    return HDB_OK;
+}
+
+extern "C" int hdb_topk(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, int metric, int64_t* dev_idx,
+                        float* dev_score, int32_t* dev_status, void* stream) {
+    return topk_impl(ix, dev_Q, nq, k, metric, dev_idx, dev_score, dev_status, stream, false);
+}
+
+extern "C" int hdb_topk_exact(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, int metric, int64_t* dev_idx,
+                              float* dev_score, int32_t* dev_status, void* stream) {
+    return topk_impl(ix, dev_Q, nq, k, metric, dev_idx, dev_score, dev_status, stream, true);
+}
+
+extern "C" int hdb_merge_topk(const int64_t* dev_idx_parts, const float* dev_score_parts, int32_t parts, int32_t nq,
+                              int32_t k, int64_t* dev_idx, float* dev_score, int device, void* stream) {
+    if (!dev_idx_parts || !dev_score_parts || !dev_idx || !dev_score) return fail(HDB_ERR_ARG, "hdb_merge_topk: null argument");
+    if (parts <= 0 || nq < 0 || k < 0) return fail(HDB_ERR_ARG, "hdb_merge_topk: bad sizes");
+    if (nq == 0 || k == 0) return HDB_OK;
+    if ((int64_t)parts * k > HDB_CAND_CAP) return fail(HDB_ERR_UNSUPPORTED, "hdb_merge_topk: parts*k exceeds 8192");
+    HIP_TRY(hipSetDevice(device));
+    LAUNCH_TRY(hdb_launch_merge(dev_idx_parts, (int64_t)nq * k * 8, dev_score_parts, (int64_t)nq * k * 4, nullptr, 0, parts, nq,
+                                (uint32_t)k, dev_idx, dev_score, nullptr, stream));
+    return HDB_OK;
+}
+
+extern "C" int64_t hdb_packed_bytes(int32_t nq, int32_t k) {
+    const int64_t raw = (int64_t)nq * k * 12 + (int64_t)nq * 4;
+    return (raw + 15) / 16 * 16;
+}
+
+extern "C" int hdb_merge_topk_packed(const void* dev_gathered, int32_t parts, int32_t nq, int32_t k, int64_t* dev_idx,
+                                     float* dev_score, int32_t* dev_status, int device, void* stream) {
+    if (!dev_gathered || !dev_idx || !dev_score) return fail(HDB_ERR_ARG, "hdb_merge_topk_packed: null argument");
+    if (parts <= 0 || nq < 0 || k < 0) return fail(HDB_ERR_ARG, "hdb_merge_topk_packed: bad sizes");
+    if (nq == 0 || k == 0) return HDB_OK;
+    if ((int64_t)parts * k > HDB_CAND_CAP) return fail(HDB_ERR_UNSUPPORTED, "hdb_merge_topk_packed: parts*k exceeds 8192");
+    HIP_TRY(hipSetDevice(device));
+    const int64_t stride = hdb_packed_bytes(nq, k);
+    const char* base = (const char*)dev_gathered;
+    LAUNCH_TRY(hdb_launch_merge(base, stride, base + (int64_t)nq * k * 8, stride, base + (int64_t)nq * k * 12, stride, parts, nq,
+                                (uint32_t)k, dev_idx, dev_score, dev_status, stream));
+    return HDB_OK;
+}
+
+extern "C" int hdb_recency_bias(const double* dev_ts, int64_t n, double recency_bias, double ts_max, float* dev_out,
+                                int device, void* stream) {
+    if (n < 0 || (n > 0 && (!dev_ts || !dev_out))) return fail(HDB_ERR_ARG, "hdb_recency_bias: null argument");
+    if (n == 0) return HDB_OK;
+    HIP_TRY(hipSetDevice(device));
+    LAUNCH_TRY(hdb_launch_recency(dev_ts, n, recency_bias, ts_max, dev_out, stream));
+    return HDB_OK;
+}

@@ -1,0 +1,99 @@
+// hdb_common.h -- shared device helpers for the gfx950 ranking kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#define HDB_WAVE 64
+
+// ---- candidate / selection geometry -------------------------------------------------------
+// Candidates that pass the per-query threshold are appended to a per-query list of CAP packed
+// 64-bit entries: (orderable score key << 32) | (0xFFFFFFFF - local row).  Sorting those
+// DEScending gives (score descending, row ascending) -- the canonical order of the build.
+#define HDB_CAND_CAP 8192
+#define HDB_RADIX_BITS 8
+#define HDB_RADIX_BINS 256
+
+struct ScanArgs {
+    const void* V;          // matrix, row-major
+    int64_t n;              // rows in V
+    int32_t d;              // elements per row
+    int32_t row_bytes;      // d * sizeof(T)
+    int32_t nchunks;        // 16-byte chunks per row (row_bytes / 16) for the vector kernels
+    const void* Q;          // queries [nq][d] in the accumulate type (float, or double for f64)
+    int32_t q0;             // first query handled by this launch (blockIdx.y adds to it)
+    int32_t metric;         // hdb_metric
+    const float* inv_norm;  // [n] 1/||v|| (cosine) or nullptr
+    const float* qinv;      // [nq] 1/||q|| (cosine) or nullptr
+    const float* bias;      // [n] or nullptr
+    const uint8_t* mask;    // [n] or nullptr
+    // row tiling: tile t covers rows [t*tile_stride*16, +16)
+    int64_t ntiles;         // number of 16-row tiles to process
+    int64_t tile_stride;    // 1 = dense scan; >1 = strided sample
+    // MODE 0 output
+    float* scores;          // [nq][ld]
+    int64_t ld;
+    // MODE 1 output
+    const float* thr;       // [nq]
+    uint32_t* cnt;          // [nq]
+    unsigned long long* cand;  // [nq][cap]
+    uint32_t cap;
+};
+
+// ---- orderable float keys -----------------------------------------------------------------
+__device__ __forceinline__ uint32_t hdb_f2key(float f) {
+    uint32_t u = __float_as_uint(f);
+    return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);   // ascending uint order == float order
+}
+__device__ __forceinline__ float hdb_key2f(uint32_t k) {
+    uint32_t u = k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu);
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ unsigned long long hdb_pack(float s, uint32_t row) {
+    return ((unsigned long long)hdb_f2key(s) << 32) | (unsigned long long)(0xFFFFFFFFu - row);
+}
+// NaN -> -inf (reference ranking_algorithm.py:174) and -0.0 -> +0.0 (so equal floats have equal keys)
+__device__ __forceinline__ float hdb_canon(float s) {
+    if (s != s) s = -INFINITY;
+    return s + 0.0f;
+}
+
+// ---- 4 row sums over a 16-lane group with DPP ---------------------------------------------------
+// Each 16-lane group holds partial sums a0..a3 of its 4 rows in every lane.  An "ownership"
+// butterfly halves the number of live values at each of the first two exchanges (xor 15 =
+// row_mirror, xor 7 = row_half_mirror), then two plain exchanges (quad_perm xor 2, xor 1) finish:
+// 5 DPP adds instead of 16, no LDS, no bpermute.  On return every lane holds the complete sum of
+// row  hdb_owned_row(l16) = 2*bit2(l16) + bit3(l16)  of its group.
+template <int CTRL>
+__device__ __forceinline__ float hdb_dpp(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ double hdb_dpp(double x) {
+    const long long b = __double_as_longlong(x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xFFFFFFFFll), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+#define HDB_DPP_MIRROR 0x140
+#define HDB_DPP_HALF_MIRROR 0x141
+#define HDB_DPP_XOR2 0x4E
+#define HDB_DPP_XOR1 0xB1
+template <typename A>
+__device__ __forceinline__ A hdb_rows4_sum(A a0, A a1, A a2, A a3, int l16) {
+    const bool b3 = (l16 & 8) != 0, b2 = (l16 & 4) != 0;
+    const A v01 = (b3 ? a1 : a0) + hdb_dpp<HDB_DPP_MIRROR>(b3 ? a0 : a1);
+    const A v23 = (b3 ? a3 : a2) + hdb_dpp<HDB_DPP_MIRROR>(b3 ? a2 : a3);
+    A w = (b2 ? v23 : v01) + hdb_dpp<HDB_DPP_HALF_MIRROR>(b2 ? v01 : v23);
+    w += hdb_dpp<HDB_DPP_XOR2>(w);
+    w += hdb_dpp<HDB_DPP_XOR1>(w);
+    return w;
+}
+__device__ __forceinline__ int hdb_owned_row(int l16) { return ((l16 >> 2) & 1) * 2 + ((l16 >> 3) & 1); }
+
+// ---- launch helpers (host) -------------------------------------------------------------------
+static inline int hdb_grid_for(int64_t work_items, int per_block, int max_blocks) {
+    int64_t b = (work_items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    return (int)(b < (int64_t)max_blocks ? b : (int64_t)max_blocks);
+}

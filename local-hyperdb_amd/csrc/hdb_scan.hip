@@ -1,0 +1,433 @@
+// hdb_scan.hip -- HBM-bound row-scan kernels (VALU path) for gfx950.
+//
+// One pass over the stored N x d matrix computes, for QT queries at a time, the metric score of
+// every row (reference: the numpy metric functions of hyperdb/ranking_algorithm.py:24-52 and
+// :128-147) and either writes it (MODE 0: per-metric functions, row sample, exact path) or
+// compares it with a per-query threshold and appends survivors to a candidate list (MODE 1: the
+// fused top-k of ranking_algorithm.py:194-200 -- the N-sized score vector is never written).
+//
+// Layout in HBM: V is the caller's C-contiguous N x d array (HyperDB.vectors).  A wave covers a
+// tile of 16 consecutive rows: lane group g = lane>>4 owns rows 4g..4g+3 of the tile and its 16
+// lanes stride over the row in 16-byte chunks (256 contiguous bytes per group per load, whole
+// 128-B lines; a d=384 fp16 row is exactly 3 such loads).  Queries sit in LDS in the accumulate
+// type; per-row sums are finished with four DPP row rotations (no LDS, no shuffles).
+// Algorithmic bytes per row = row_bytes (+4 for the cached 1/||v||, +4 bias when set).
+#include "hdb_common.h"
+#include "../../include/hyperdb_hip.h"
+
+template <typename T> struct Elem;
+template <> struct Elem<__half> { using Acc = float;  static constexpr int EPC = 8; };
+template <> struct Elem<float>  { using Acc = float;  static constexpr int EPC = 4; };
+template <> struct Elem<double> { using Acc = double; static constexpr int EPC = 2; };
+
+__device__ __forceinline__ void hdb_unpack(const uint4& raw, float (&x)[8], __half*) {
+    const __half2* h = reinterpret_cast<const __half2*>(&raw);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { float2 f = __half22float2(h[i]); x[2 * i] = f.x; x[2 * i + 1] = f.y; }
+}
+__device__ __forceinline__ void hdb_unpack(const uint4& raw, float (&x)[4], float*) {
+    x[0] = __uint_as_float(raw.x); x[1] = __uint_as_float(raw.y);
+    x[2] = __uint_as_float(raw.z); x[3] = __uint_as_float(raw.w);
+}
+__device__ __forceinline__ void hdb_unpack(const uint4& raw, double (&x)[2], double*) {
+    x[0] = __longlong_as_double(((unsigned long long)raw.y << 32) | raw.x);
+    x[1] = __longlong_as_double(((unsigned long long)raw.w << 32) | raw.z);
+}
+
+__device__ __forceinline__ float hdb_to_f(__half v) { return __half2float(v); }
+__device__ __forceinline__ float hdb_to_f(float v) { return v; }
+__device__ __forceinline__ double hdb_to_f(double v) { return v; }
+
+// Shared epilogue: raw row sum -> final score of hyperDB_ranking_algorithm_sort, then store / filter.
+template <int MODE, typename Acc>
+__device__ __forceinline__ void hdb_emit(const ScanArgs& a, int q, int64_t row, int64_t out_i, Acc sum) {
+    float s;
+    if (a.metric == HDB_EUCLIDEAN) {
+        s = (float)(Acc(1) / (Acc(1) + sqrt(sum)));                       // 1/(1+||v-q||), :49-51
+    } else if (a.metric == HDB_EUCLIDEAN_DIST) {
+        s = (float)sqrt(sum);
+    } else if (a.metric == HDB_COSINE) {
+        s = (float)sum * a.inv_norm[row] * a.qinv[q];                      // :37-41 with cached norms
+    } else {
+        s = (float)sum;                                                    // dot / hamming
+    }
+    if (a.bias) s += a.bias[row];                                          // recency, :186
+    const bool masked = a.mask && !a.mask[row];                            // filtered-out row
+    if (masked) s = -INFINITY;
+    s = hdb_canon(s);                                                      // NaN -> -inf, :174
+    if (MODE == 0) {
+        a.scores[(int64_t)(q - a.q0) * a.ld + out_i] = s;
+    } else {
+        const int ql = q - a.q0;
+        if (!masked && s >= a.thr[ql]) {
+            const uint32_t pos = atomicAdd(&a.cnt[ql], 1u);
+            if (pos < a.cap) a.cand[(int64_t)ql * a.cap + pos] = hdb_pack(s, (uint32_t)row);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Vector scan: rows are multiples of 16 bytes and V is 16-byte aligned.
+// grid = (blocks, ceil(nq_launch / QT)); block = 256 threads = 4 waves; LDS = QT*d*sizeof(Acc).
+// NJ > 0: compile-time number of 16-chunk steps per row (d*sizeof(T) == NJ*256), fully unrolled so
+// that all 4*NJ loads of a tile are in flight together; NJ == 0: runtime loop, any nchunks.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int QT, int MODE, bool EUCLID, int NJ>
+__global__ __launch_bounds__(256) void hdb_scan_kernel(ScanArgs a, int nq_end) {
+    using Acc = typename Elem<T>::Acc;
+    constexpr int EPC = Elem<T>::EPC;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Acc* qs = reinterpret_cast<Acc*>(smem);
+
+    const int qbase = a.q0 + blockIdx.y * QT;
+    for (int i = threadIdx.x; i < QT * a.d; i += 256) {
+        const int qt = i / a.d, e = i - qt * a.d;
+        const int q = min(qbase + qt, nq_end - 1);
+        qs[i] = reinterpret_cast<const Acc*>(a.Q)[(int64_t)q * a.d + e];
+    }
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, l16 = lane & 15;
+    const int nj = NJ > 0 ? NJ : (a.nchunks + 15) >> 4;
+    const char* Vb = reinterpret_cast<const char*>(a.V);
+
+    for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < a.ntiles; t += (int64_t)gridDim.x * 4) {
+        const int64_t r0 = t * a.tile_stride * 16 + 4 * g;
+        const char* p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t r = min(r0 + u, a.n - 1);
+            p[u] = Vb + r * (int64_t)a.row_bytes;
+        }
+        Acc acc[4][QT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) acc[u][qt] = Acc(0);
+
+        auto step = [&](int j) {
+            const int c = l16 + 16 * j;
+            const bool live = NJ > 0 ? true : (c < a.nchunks);
+            const int cc = live ? c : a.nchunks - 1;
+            uint4 raw[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const uint4*>(p[u] + (int64_t)cc * 16);
+            Acc x[4][EPC];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                hdb_unpack(raw[u], x[u], (T*)nullptr);
+            }
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                Acc qv[EPC];
+#pragma unroll
+                for (int e = 0; e < EPC; ++e) qv[e] = qs[qt * a.d + cc * EPC + e];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) {
+                        // lanes past the end of a ragged row (live == false) contribute exactly 0
+                        if (EUCLID) {
+                            const Acc df = live ? x[u][e] - qv[e] : Acc(0);
+                            acc[u][qt] += df * df;
+                        } else {
+                            acc[u][qt] += (live ? x[u][e] : Acc(0)) * qv[e];
+                        }
+                    }
+                }
+            }
+        };
+        if constexpr (NJ > 0) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) step(j);
+        } else {
+            for (int j = 0; j < nj; ++j) step(j);
+        }
+        // finish the 16-lane row sums; lane l16==u keeps row u of its group
+        const int u_own = hdb_owned_row(l16);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const Acc mine = hdb_rows4_sum(acc[0][qt], acc[1][qt], acc[2][qt], acc[3][qt], l16);
+            const int64_t row = r0 + u_own;
+            const int q = qbase + qt;
+            if ((l16 & 3) == 0 && row < a.n && q < nq_end)
+                hdb_emit<MODE>(a, q, row, t * 16 + 4 * g + u_own, mine);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic scan: any d / alignment (element-wise loads).  Same tiling, one query per launch row.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int MODE, bool EUCLID>
+__global__ __launch_bounds__(256) void hdb_scan_generic_kernel(ScanArgs a, int nq_end) {
+    using Acc = typename Elem<T>::Acc;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    Acc* qs = reinterpret_cast<Acc*>(smem);
+    const int q = a.q0 + blockIdx.y;
+    for (int i = threadIdx.x; i < a.d; i += 256) qs[i] = reinterpret_cast<const Acc*>(a.Q)[(int64_t)q * a.d + i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, l16 = lane & 15;
+    const T* Vt = reinterpret_cast<const T*>(a.V);
+    for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < a.ntiles; t += (int64_t)gridDim.x * 4) {
+        const int64_t r0 = t * a.tile_stride * 16 + 4 * g;
+        Acc acc[4] = {Acc(0), Acc(0), Acc(0), Acc(0)};
+        for (int e = l16; e < a.d; e += 16) {
+            const Acc qv = qs[e];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t r = min(r0 + u, a.n - 1);
+                const Acc x = (Acc)hdb_to_f(Vt[r * (int64_t)a.d + e]);
+                if (EUCLID) { const Acc df = x - qv; acc[u] += df * df; }
+                else acc[u] += x * qv;
+            }
+        }
+        const int u_own = hdb_owned_row(l16);
+        const Acc mine = hdb_rows4_sum(acc[0], acc[1], acc[2], acc[3], l16);
+        const int64_t row = r0 + u_own;
+        if ((l16 & 3) == 0 && row < a.n && q < nq_end) hdb_emit<MODE>(a, q, row, t * 16 + 4 * g + u_own, mine);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row caches: 1/||v|| (norm 0 -> 1, ranking_algorithm.py:11-15), ||v||^2, NaN flag (:150).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void hdb_rownorm_kernel(const T* V, int64_t n, int d, float* inv_norm,
+                                                          float* sqnorm, int* nan_flag) {
+    using Acc = typename Elem<T>::Acc;
+    constexpr int EPC = Elem<T>::EPC;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, l16 = lane & 15;
+    const int64_t ntiles = (n + 15) / 16;
+    const bool vec = ((d * (int)sizeof(T)) % 16 == 0) && ((reinterpret_cast<uintptr_t>(V) & 15) == 0);
+    const int nchunks = d * (int)sizeof(T) / 16;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += (int64_t)gridDim.x * 4) {
+        const int64_t r0 = t * 16 + 4 * g;
+        Acc acc[4] = {Acc(0), Acc(0), Acc(0), Acc(0)};
+        if (vec) {
+            for (int c = l16; c < nchunks; c += 16) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t r = min(r0 + u, n - 1);
+                    const uint4 raw = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(V) + r * (int64_t)d * sizeof(T) + (int64_t)c * 16);
+                    Acc x[EPC];
+                    hdb_unpack(raw, x, (T*)nullptr);
+#pragma unroll
+                    for (int e = 0; e < EPC; ++e) acc[u] += x[e] * x[e];
+                }
+            }
+        } else {
+            for (int e = l16; e < d; e += 16) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t r = min(r0 + u, n - 1);
+                    const Acc x = (Acc)hdb_to_f(V[r * (int64_t)d + e]);
+                    acc[u] += x * x;
+                }
+            }
+        }
+        const Acc mine = hdb_rows4_sum(acc[0], acc[1], acc[2], acc[3], l16);
+        const int64_t row = r0 + hdb_owned_row(l16);
+        if ((l16 & 3) == 0 && row < n) {
+            const float ss = (float)mine;
+            if (ss != ss) atomicOr(nan_flag, 1);
+            sqnorm[row] = ss;
+            inv_norm[row] = (mine == Acc(0)) ? 1.0f : (float)(Acc(1) / sqrt(mine));
+        }
+    }
+}
+
+// Per-query prep: qinv = 1/||q|| (0 -> 1), qsq = ||q||^2, NaN flag.  One wave per query.
+template <typename Acc>
+__global__ __launch_bounds__(64) void hdb_qprep_kernel(const Acc* Q, int nq, int d, float* qinv, float* qsq, int* qnan) {
+    const int q = blockIdx.x;
+    if (q >= nq) return;
+    Acc s = Acc(0);
+    for (int e = threadIdx.x; e < d; e += 64) { const Acc x = Q[(int64_t)q * d + e]; s += x * x; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (threadIdx.x == 0) {
+        const float ss = (float)s;
+        qsq[q] = ss;
+        qinv[q] = (s == Acc(0)) ? 1.0f : (float)(Acc(1) / sqrt(s));
+        qnan[q] = (ss != ss) ? 1 : 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Hamming (ranking_algorithm.py:116-147): binarise by x > 0, similarity = d - popcount(v ^ q).
+// Sign bits are packed once per matrix, word-major: bits[w][row] (row pitch npad, multiple of 4)
+// so that a scan thread handling rows 4i..4i+3 reads one uint4 per word, fully coalesced.
+// Algorithmic bytes per row = 4 * ceil(d/32).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void hdb_signpack_kernel(const T* V, int64_t n, int d, int64_t npad, uint32_t* bits) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
+    for (int64_t r = wave; r < n; r += nwaves) {
+        for (int e0 = 0; e0 < d; e0 += 64) {
+            const int e = e0 + lane;
+            const bool pos = (e < d) && (hdb_to_f(V[r * (int64_t)d + e]) > 0);
+            const unsigned long long m = __ballot(pos);
+            if (lane == 0) {
+                bits[(int64_t)(e0 >> 5) * npad + r] = (uint32_t)m;
+                if (e0 + 32 < d) bits[(int64_t)((e0 >> 5) + 1) * npad + r] = (uint32_t)(m >> 32);
+            }
+        }
+    }
+}
+
+template <typename Acc>
+__global__ __launch_bounds__(64) void hdb_qsign_kernel(const Acc* Q, int nq, int d, int W, uint32_t* qbits) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    for (int e0 = 0; e0 < d; e0 += 64) {
+        const int e = e0 + lane;
+        const bool pos = (e < d) && (Q[(int64_t)q * d + e] > 0);
+        const unsigned long long m = __ballot(pos);
+        if (lane == 0) {
+            qbits[(int64_t)q * W + (e0 >> 5)] = (uint32_t)m;
+            if (e0 + 32 < d) qbits[(int64_t)q * W + (e0 >> 5) + 1] = (uint32_t)(m >> 32);
+        }
+    }
+}
+
+// grid = (blocks, nq); each thread owns 4 consecutive rows.
+template <int MODE>
+__global__ __launch_bounds__(256) void hdb_hamming_kernel(ScanArgs a, const uint32_t* bits, int64_t npad, int W,
+                                                          const uint32_t* qbits, int nq_end) {
+    __shared__ uint32_t qb[512];
+    const int q = a.q0 + blockIdx.y;
+    for (int w = threadIdx.x; w < W; w += 256) qb[w] = qbits[(int64_t)q * W + w];
+    __syncthreads();
+    const int64_t nquads = (a.n + 3) / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nquads; i += (int64_t)gridDim.x * 256) {
+        uint32_t mism[4] = {0, 0, 0, 0};
+        for (int w = 0; w < W; ++w) {
+            const uint4 v = *reinterpret_cast<const uint4*>(bits + (int64_t)w * npad + 4 * i);
+            const uint32_t qq = qb[w];
+            mism[0] += __popc(v.x ^ qq); mism[1] += __popc(v.y ^ qq);
+            mism[2] += __popc(v.z ^ qq); mism[3] += __popc(v.w ^ qq);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t row = 4 * i + u;
+            if (row < a.n && q < nq_end) hdb_emit<MODE>(a, q, row, row, (float)(a.d - (int)mism[u]));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side launchers
+// ------------------------------------------------------------------------------------------------
+template <typename T, int QT, int MODE, bool EUCLID>
+static void launch_vec(const ScanArgs& a, int nq_launch, int blocks, hipStream_t st) {
+    using Acc = typename Elem<T>::Acc;
+    const dim3 grid(blocks, (nq_launch + QT - 1) / QT);
+    const size_t lds = (size_t)QT * a.d * sizeof(Acc);
+    const int nq_end = a.q0 + nq_launch;
+    if constexpr (QT == 1) {   // fully unrolled variants only for one query: with QT=4 they spill
+        const int nj = (a.nchunks % 16 == 0) ? a.nchunks / 16 : 0;
+        if (nj == 3) { hipLaunchKernelGGL((hdb_scan_kernel<T, QT, MODE, EUCLID, 3>), grid, dim3(256), lds, st, a, nq_end); return; }
+        if (nj == 6) { hipLaunchKernelGGL((hdb_scan_kernel<T, QT, MODE, EUCLID, 6>), grid, dim3(256), lds, st, a, nq_end); return; }
+    }
+    hipLaunchKernelGGL((hdb_scan_kernel<T, QT, MODE, EUCLID, 0>), grid, dim3(256), lds, st, a, nq_end);
+}
+
+template <typename T, int MODE>
+static void launch_scan_t(const ScanArgs& a, int nq_launch, int blocks, bool vec, hipStream_t st) {
+    using Acc = typename Elem<T>::Acc;
+    const bool euclid = (a.metric == HDB_EUCLIDEAN || a.metric == HDB_EUCLIDEAN_DIST);
+    const size_t lds4 = (size_t)4 * a.d * sizeof(Acc);
+    if (!vec) {
+        const dim3 grid(blocks, nq_launch);
+        const size_t lds = (size_t)a.d * sizeof(Acc);
+        const int nq_end = a.q0 + nq_launch;
+        if (euclid) hipLaunchKernelGGL((hdb_scan_generic_kernel<T, MODE, true>), grid, dim3(256), lds, st, a, nq_end);
+        else hipLaunchKernelGGL((hdb_scan_generic_kernel<T, MODE, false>), grid, dim3(256), lds, st, a, nq_end);
+        return;
+    }
+    const bool qt4 = nq_launch >= 3 && lds4 <= 60 * 1024;
+    if (qt4) {
+        if (euclid) launch_vec<T, 4, MODE, true>(a, nq_launch, blocks, st);
+        else launch_vec<T, 4, MODE, false>(a, nq_launch, blocks, st);
+    } else {
+        if (euclid) launch_vec<T, 1, MODE, true>(a, nq_launch, blocks, st);
+        else launch_vec<T, 1, MODE, false>(a, nq_launch, blocks, st);
+    }
+}
+
+// Entry used by hdb_api.hip.  mode: 0 = write scores, 1 = threshold filter.
+extern "C" int hdb_launch_scan(const ScanArgs* args, int dtype, int mode, int nq_launch, int max_blocks, void* stream) {
+    ScanArgs a = *args;
+    hipStream_t st = (hipStream_t)stream;
+    const int elem = dtype == HDB_F16 ? 2 : dtype == HDB_F32 ? 4 : 8;
+    a.row_bytes = a.d * elem;
+    a.nchunks = a.row_bytes / 16;
+    const bool vec = (a.row_bytes % 16 == 0) && ((reinterpret_cast<uintptr_t>(a.V) & 15) == 0) &&
+                     ((size_t)a.d * (elem == 8 ? 8 : 4) <= 60 * 1024);
+    const int blocks = hdb_grid_for(a.ntiles, 4, max_blocks);
+    if (dtype == HDB_F16) { if (mode == 0) launch_scan_t<__half, 0>(a, nq_launch, blocks, vec, st); else launch_scan_t<__half, 1>(a, nq_launch, blocks, vec, st); }
+    else if (dtype == HDB_F32) { if (mode == 0) launch_scan_t<float, 0>(a, nq_launch, blocks, vec, st); else launch_scan_t<float, 1>(a, nq_launch, blocks, vec, st); }
+    else { if (mode == 0) launch_scan_t<double, 0>(a, nq_launch, blocks, vec, st); else launch_scan_t<double, 1>(a, nq_launch, blocks, vec, st); }
+    return (int)hipGetLastError();
+}
+
+extern "C" int hdb_launch_rownorm(const void* V, int64_t n, int d, int dtype, float* inv_norm, float* sqnorm,
+                                  int* nan_flag, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = hdb_grid_for((n + 15) / 16, 4, 2048);
+    if (dtype == HDB_F16) hipLaunchKernelGGL(hdb_rownorm_kernel<__half>, dim3(blocks), dim3(256), 0, st, (const __half*)V, n, d, inv_norm, sqnorm, nan_flag);
+    else if (dtype == HDB_F32) hipLaunchKernelGGL(hdb_rownorm_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)V, n, d, inv_norm, sqnorm, nan_flag);
+    else hipLaunchKernelGGL(hdb_rownorm_kernel<double>, dim3(blocks), dim3(256), 0, st, (const double*)V, n, d, inv_norm, sqnorm, nan_flag);
+    return (int)hipGetLastError();
+}
+
+extern "C" int hdb_launch_qprep(const void* Q, int nq, int d, bool f64, float* qinv, float* qsq, int* qnan, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (f64) hipLaunchKernelGGL(hdb_qprep_kernel<double>, dim3(nq), dim3(64), 0, st, (const double*)Q, nq, d, qinv, qsq, qnan);
+    else hipLaunchKernelGGL(hdb_qprep_kernel<float>, dim3(nq), dim3(64), 0, st, (const float*)Q, nq, d, qinv, qsq, qnan);
+    return (int)hipGetLastError();
+}
+
+extern "C" int hdb_launch_signpack(const void* V, int64_t n, int d, int dtype, int64_t npad, uint32_t* bits, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = hdb_grid_for(n, 4, 4096);
+    if (dtype == HDB_F16) hipLaunchKernelGGL(hdb_signpack_kernel<__half>, dim3(blocks), dim3(256), 0, st, (const __half*)V, n, d, npad, bits);
+    else if (dtype == HDB_F32) hipLaunchKernelGGL(hdb_signpack_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)V, n, d, npad, bits);
+    else hipLaunchKernelGGL(hdb_signpack_kernel<double>, dim3(blocks), dim3(256), 0, st, (const double*)V, n, d, npad, bits);
+    return (int)hipGetLastError();
+}
+
+extern "C" int hdb_launch_qsign(const void* Q, int nq, int d, bool f64, int W, uint32_t* qbits, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (f64) hipLaunchKernelGGL(hdb_qsign_kernel<double>, dim3(nq), dim3(64), 0, st, (const double*)Q, nq, d, W, qbits);
+    else hipLaunchKernelGGL(hdb_qsign_kernel<float>, dim3(nq), dim3(64), 0, st, (const float*)Q, nq, d, W, qbits);
+    return (int)hipGetLastError();
+}
+
+extern "C" int hdb_launch_hamming(const ScanArgs* args, int mode, int nq_launch, const uint32_t* bits, int64_t npad,
+                                  int W, const uint32_t* qbits, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const ScanArgs& a = *args;
+    const dim3 grid(hdb_grid_for((a.n + 3) / 4, 256, 2048), nq_launch);
+    const int nq_end = a.q0 + nq_launch;
+    if (mode == 0) hipLaunchKernelGGL(hdb_hamming_kernel<0>, grid, dim3(256), 0, st, a, bits, npad, W, qbits, nq_end);
+    else hipLaunchKernelGGL(hdb_hamming_kernel<1>, grid, dim3(256), 0, st, a, bits, npad, W, qbits, nq_end);
+    return (int)hipGetLastError();
+}
+
+// Recency term of hyperDB_ranking_algorithm_sort (ranking_algorithm.py:180-183):
+// bias[i] = recency_bias * exp(ts[i] - max(ts)), difference and exp in float64 (unix-second
+// timestamps lose ~100 s of resolution in float32), result stored as float32.
+__global__ __launch_bounds__(256) void hdb_recency_kernel(const double* ts, int64_t n, double rb, double ts_max, float* out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = (float)(rb * exp(ts[i] - ts_max));
+}
+extern "C" int hdb_launch_recency(const double* ts, int64_t n, double rb, double ts_max, float* out, void* stream) {
+    hipLaunchKernelGGL(hdb_recency_kernel, dim3(hdb_grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, ts, n, rb, ts_max, out);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,338 @@
+// hdb_select.hip -- top-k selection kernels for gfx950 (the np.argpartition + np.argsort of
+// hyperdb/ranking_algorithm.py:194-200, restated for a GPU).
+//
+// Ordering rule everywhere: (score descending, row index ascending) -- a total order, so the
+// top-k is unique and independent of launch geometry and of the number of GPUs.
+//
+//  * radix histogram passes over a dense float score array (8 bits per pass on the orderable
+//    key).  After 2 passes the lower edge of the bin holding the m-th largest SAMPLE score is a
+//    safe per-query threshold for the fused scan; after 4 passes the k-th largest key is exact.
+//  * collect: everything above the k-th key plus its ties -> candidate list (exact path).
+//  * ordered tie scan: when the k-th key has more ties than the candidate list can hold, one
+//    workgroup walks the array in index order and keeps the first `need` of them.
+//  * finalize: one workgroup per query bitonic-sorts <= 8192 packed candidates in LDS and writes
+//    the first k as (int64 index + row_base, float score).
+//  * merge: the same sort over the all-gathered per-shard lists (multi-GPU exchange step).
+//
+// No state survives between kernels except the histograms: each kernel re-derives the radix
+// prefix from hist[q][0..pass) in its prologue, so kernel boundaries provide all the ordering.
+#include "hdb_common.h"
+#include "../../include/hyperdb_hip.h"
+
+// hist layout: [nq][4][256] uint32
+struct Prefix { uint32_t key; uint32_t need; uint32_t bin_count; };
+
+// Executed by wave 0 of a block.  Walks passes [0, npass): in each, finds (from the top) the bin
+// holding the `need`-th largest remaining key.  Returns the key prefix (low bits zero), how many
+// are still needed from inside that bin, and the population of the final bin.
+__device__ Prefix hdb_derive_prefix(const uint32_t* hist_q, int npass, uint32_t k, int lane) {
+    uint32_t key = 0, need = k, bin_count = 0;
+    for (int p = 0; p < npass; ++p) {
+        const uint32_t* h = hist_q + p * HDB_RADIX_BINS;
+        // lane owns descending bins 255-4*lane .. 252-4*lane
+        uint32_t c[4], tot = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { c[j] = h[255 - (4 * lane + j)]; tot += c[j]; }
+        uint32_t incl = tot;                       // inclusive scan over lanes
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += v;
+        }
+        uint32_t before = incl - tot;              // keys in bins above this lane's bins
+        int found_bin = -1; uint32_t found_before = 0, found_cnt = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (found_bin < 0 && before < need && need <= before + c[j]) {
+                found_bin = 255 - (4 * lane + j); found_before = before; found_cnt = c[j];
+            }
+            before += c[j];
+        }
+        const unsigned long long who = __ballot(found_bin >= 0);
+        int src = who ? (int)__ffsll((long long)who) - 1 : 63;
+        int bin = __shfl(found_bin, src, 64);
+        uint32_t fb = __shfl(found_before, src, 64);
+        uint32_t fc = __shfl(found_cnt, src, 64);
+        if (!who) { bin = 0; fb = 0; fc = 0; }     // fewer keys than needed: take everything
+        key |= (uint32_t)bin << (24 - 8 * p);
+        need = who ? need - fb : need;
+        bin_count = fc;
+    }
+    Prefix r; r.key = key; r.need = need; r.bin_count = bin_count;
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Histogram pass.  grid = (blocks, nq).  Keys not matching the prefix of earlier passes are skipped.
+// Wave-aggregated LDS atomics: lanes with the same bin elect one adder (score keys cluster in a
+// handful of exponent bins, which would serialise plain atomics).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hdb_hist_kernel(const float* scores, int64_t n, int64_t ld, uint32_t* hist,
+                                                       int pass, uint32_t k) {
+    __shared__ uint32_t lh[HDB_RADIX_BINS];
+    __shared__ uint32_t s_prefix;
+    const int q = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    lh[threadIdx.x] = 0;
+    if (threadIdx.x < 64) {
+        const Prefix pf = hdb_derive_prefix(hist + (int64_t)q * 4 * HDB_RADIX_BINS, pass, k, lane);
+        if (lane == 0) s_prefix = pf.key;
+    }
+    __syncthreads();
+    const uint32_t prefix = s_prefix;
+    const uint32_t mask = pass == 0 ? 0u : (0xFFFFFFFFu << (32 - 8 * pass));
+    const int shift = 24 - 8 * pass;
+    const float* sq = scores + (int64_t)q * ld;
+    const int64_t nround = (n + 255) / 256 * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nround; i += (int64_t)gridDim.x * 256) {
+        bool active = i < n;
+        uint32_t bin = 0;
+        if (active) {
+            const uint32_t key = hdb_f2key(sq[i]);
+            active = (key & mask) == prefix;
+            bin = (key >> shift) & 255u;
+        }
+        unsigned long long todo = __ballot(active);
+        while (todo) {
+            const int leader = (int)__ffsll((long long)todo) - 1;
+            const uint32_t lb = __shfl(bin, leader, 64);
+            const unsigned long long same = __ballot(active && bin == lb);
+            if (lane == leader) atomicAdd(&lh[lb], (uint32_t)__popcll(same));
+            todo &= ~same;
+        }
+    }
+    __syncthreads();
+    const uint32_t c = lh[threadIdx.x];
+    if (c) atomicAdd(&hist[((int64_t)q * 4 + pass) * HDB_RADIX_BINS + threadIdx.x], c);
+}
+
+// Threshold from the sample histograms: lower edge of the bin holding the m-th largest sample score
+// after `npass` passes (so at least m sample scores are >= thr).  Also resets the candidate counter.
+// One wave per query.
+__global__ __launch_bounds__(64) void hdb_thr_kernel(const uint32_t* hist, int npass, uint32_t m, uint32_t sample_n,
+                                                     float* thr, uint32_t* cnt) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const Prefix pf = hdb_derive_prefix(hist + (int64_t)q * 4 * HDB_RADIX_BINS, npass, m, lane);
+    if (lane == 0) {
+        thr[q] = (sample_n < m) ? -INFINITY : hdb_key2f(pf.key);
+        cnt[q] = 0;
+    }
+}
+
+__global__ void hdb_fill_thr_kernel(float* thr, uint32_t* cnt, int nq, float v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nq) { thr[i] = v; cnt[i] = 0; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exact path: collect keys above the k-th key, and its ties when they fit.
+// tie_info[q] = {kth key, need (ties still wanted), ties_all flag, count_gt}
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hdb_collect_kernel(const float* scores, int64_t n, int64_t ld, const uint32_t* hist,
+                                                          uint32_t k, uint32_t* cnt, unsigned long long* cand,
+                                                          uint32_t cap, uint32_t* tie_info) {
+    __shared__ uint32_t s_key, s_need, s_all;
+    const int q = blockIdx.y, lane = threadIdx.x & 63;
+    if (threadIdx.x < 64) {
+        const Prefix pf = hdb_derive_prefix(hist + (int64_t)q * 4 * HDB_RADIX_BINS, 4, k, lane);
+        if (lane == 0) {
+            const uint32_t count_gt = k - pf.need;
+            const uint32_t all = (count_gt + pf.bin_count <= cap) ? 1u : 0u;
+            s_key = pf.key; s_need = pf.need; s_all = all;
+            if (blockIdx.x == 0) {
+                tie_info[q * 4 + 0] = pf.key; tie_info[q * 4 + 1] = pf.need;
+                tie_info[q * 4 + 2] = all;    tie_info[q * 4 + 3] = count_gt;
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t kth = s_key;
+    const bool ties_all = s_all != 0;
+    const float* sq = scores + (int64_t)q * ld;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float s = sq[i];
+        const uint32_t key = hdb_f2key(s);
+        if (key > kth || (ties_all && key == kth)) {
+            const uint32_t pos = atomicAdd(&cnt[q], 1u);
+            if (pos < cap) cand[(int64_t)q * cap + pos] = hdb_pack(s, (uint32_t)i);
+        }
+    }
+}
+
+// Ordered tie scan (only when ties did not fit): first `need` rows, in index order, whose key
+// equals the k-th key.  One workgroup of 1024 threads per query, stops as soon as it has enough.
+__global__ __launch_bounds__(1024) void hdb_ties_seq_kernel(const float* scores, int64_t n, int64_t ld, uint32_t* cnt,
+                                                            unsigned long long* cand, uint32_t cap, const uint32_t* tie_info) {
+    const int q = blockIdx.x;
+    if (tie_info[q * 4 + 2]) return;                      // ties were all collected already
+    const uint32_t kth = tie_info[q * 4 + 0], need = tie_info[q * 4 + 1], count_gt = tie_info[q * 4 + 3];
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t s_taken;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_taken = 0;
+    __syncthreads();
+    const float* sq = scores + (int64_t)q * ld;
+    for (int64_t base = 0; base < n; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const bool hit = (i < n) && hdb_f2key(sq[i]) == kth;
+        const unsigned long long b = __ballot(hit);
+        if (lane == 0) wsum[wave] = (uint32_t)__popcll(b);
+        __syncthreads();
+        uint32_t before = s_taken;
+        for (int w = 0; w < wave; ++w) before += wsum[w];
+        const uint32_t rank = before + (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+        if (hit && rank < need) {
+            // slots [count_gt, count_gt+need) are reserved for ties: deterministic placement
+            cand[(int64_t)q * cap + count_gt + rank] = hdb_pack(sq[i], (uint32_t)i);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+            for (int w = 0; w < 16; ++w) tot += wsum[w];
+            s_taken += tot;
+        }
+        __syncthreads();
+        if (s_taken >= need) break;
+    }
+    if (threadIdx.x == 0) cnt[q] = count_gt + need;       // > kth entries occupy [0, count_gt)
+}
+
+// ------------------------------------------------------------------------------------------------
+// Finalize: sort the candidate list of one query (<= HDB_CAND_CAP packed entries) descending and
+// emit the first k.  1024 threads, 64 KiB of LDS.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void hdb_bitonic_desc(unsigned long long* buf, int P) {
+    for (int size = 2; size <= P; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < (P >> 1); t += blockDim.x) {
+                const int i = ((t / stride) * (stride << 1)) + (t % stride);
+                const int j = i + stride;
+                const bool desc = (i & size) == 0;
+                const unsigned long long x = buf[i], y = buf[j];
+                if (desc ? (x < y) : (x > y)) { buf[i] = y; buf[j] = x; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void hdb_finalize_kernel(const unsigned long long* cand, const uint32_t* cnt,
+                                                            uint32_t cap, uint32_t k, uint32_t kk /* min(k, n) */,
+                                                            int64_t row_base, int64_t* idx_out, float* score_out,
+                                                            int32_t* status, const int* qnan) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long buf[];
+    const int q = blockIdx.x;
+    const uint32_t total = cnt[q];
+    const uint32_t nc = total < cap ? total : cap;
+    int P = 64;
+    while ((uint32_t)P < nc) P <<= 1;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) buf[i] = (uint32_t)i < nc ? cand[(int64_t)q * cap + i] : 0ull;
+    __syncthreads();
+    hdb_bitonic_desc(buf, P);
+    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
+        if (i < nc && i < kk) {
+            const unsigned long long e = buf[i];
+            idx_out[(int64_t)q * k + i] = row_base + (int64_t)(0xFFFFFFFFu - (uint32_t)(e & 0xFFFFFFFFull));
+            score_out[(int64_t)q * k + i] = hdb_key2f((uint32_t)(e >> 32));
+        } else {
+            idx_out[(int64_t)q * k + i] = -1;
+            score_out[(int64_t)q * k + i] = -INFINITY;
+        }
+    }
+    if (threadIdx.x == 0 && status) {
+        int32_t st = 0;
+        if (total > cap) st |= HDB_Q_OVERFLOW;
+        if (nc < kk) st |= HDB_Q_UNDERFLOW;
+        if (qnan && qnan[q]) st |= 4;
+        status[q] = st;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Merge of per-shard lists: parts x k candidates per query.  Shard p's rows precede shard p+1's
+// (contiguous row sharding) and each list is already in canonical order, so position p*k+i is a
+// valid tie-break for equal scores.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void hdb_merge_kernel(const char* idx_base, int64_t idx_stride, const char* score_base,
+                                                         int64_t score_stride, const char* status_base, int64_t status_stride,
+                                                         int parts, int nq, uint32_t k, int64_t* idx_out, float* score_out,
+                                                         int32_t* status_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long buf[];
+    const int q = blockIdx.x;
+    const uint32_t total = (uint32_t)parts * k;
+    int P = 64;
+    while ((uint32_t)P < total) P <<= 1;
+    for (int i = threadIdx.x; i < P; i += blockDim.x) {
+        unsigned long long e = 0ull;
+        if ((uint32_t)i < total) {
+            const int p = i / k, j = i - p * k;
+            const int64_t off = (int64_t)q * k + j;
+            const int64_t id = reinterpret_cast<const int64_t*>(idx_base + (int64_t)p * idx_stride)[off];
+            const float sc = reinterpret_cast<const float*>(score_base + (int64_t)p * score_stride)[off];
+            if (id >= 0) e = hdb_pack(sc, (uint32_t)i);   // key(-inf) > 0, so real rows never look like padding
+        }
+        buf[i] = e;
+    }
+    __syncthreads();
+    hdb_bitonic_desc(buf, P);
+    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
+        const unsigned long long e = buf[i];
+        if (e != 0ull) {
+            const uint32_t pos = 0xFFFFFFFFu - (uint32_t)(e & 0xFFFFFFFFull);
+            const int p = pos / k, j = pos - p * k;
+            const int64_t off = (int64_t)q * k + j;
+            idx_out[(int64_t)q * k + i] = reinterpret_cast<const int64_t*>(idx_base + (int64_t)p * idx_stride)[off];
+            score_out[(int64_t)q * k + i] = reinterpret_cast<const float*>(score_base + (int64_t)p * score_stride)[off];
+        } else {
+            idx_out[(int64_t)q * k + i] = -1;
+            score_out[(int64_t)q * k + i] = -INFINITY;
+        }
+    }
+    if (threadIdx.x == 0 && status_out) {
+        int32_t st = 0;
+        if (status_base)
+            for (int p = 0; p < parts; ++p) st |= reinterpret_cast<const int32_t*>(status_base + (int64_t)p * status_stride)[q];
+        status_out[q] = st;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side launchers
+// ------------------------------------------------------------------------------------------------
+extern "C" int hdb_launch_hist(const float* scores, int64_t n, int64_t ld, int nq, uint32_t* hist, int pass, uint32_t k, void* stream) {
+    const dim3 grid(hdb_grid_for(n, 256 * 8, 1024), nq);
+    hipLaunchKernelGGL(hdb_hist_kernel, grid, dim3(256), 0, (hipStream_t)stream, scores, n, ld, hist, pass, k);
+    return (int)hipGetLastError();
+}
+extern "C" int hdb_launch_thr(const uint32_t* hist, int nq, int npass, uint32_t m, uint32_t sample_n, float* thr, uint32_t* cnt, void* stream) {
+    hipLaunchKernelGGL(hdb_thr_kernel, dim3(nq), dim3(64), 0, (hipStream_t)stream, hist, npass, m, sample_n, thr, cnt);
+    return (int)hipGetLastError();
+}
+extern "C" int hdb_launch_fill_thr(float* thr, uint32_t* cnt, int nq, float v, void* stream) {
+    hipLaunchKernelGGL(hdb_fill_thr_kernel, dim3((nq + 255) / 256), dim3(256), 0, (hipStream_t)stream, thr, cnt, nq, v);
+    return (int)hipGetLastError();
+}
+extern "C" int hdb_launch_collect(const float* scores, int64_t n, int64_t ld, int nq, const uint32_t* hist, uint32_t k,
+                                  uint32_t* cnt, unsigned long long* cand, uint32_t cap, uint32_t* tie_info, void* stream) {
+    const dim3 grid(hdb_grid_for(n, 256 * 8, 1024), nq);
+    hipLaunchKernelGGL(hdb_collect_kernel, grid, dim3(256), 0, (hipStream_t)stream, scores, n, ld, hist, k, cnt, cand, cap, tie_info);
+    hipLaunchKernelGGL(hdb_ties_seq_kernel, dim3(nq), dim3(1024), 0, (hipStream_t)stream, scores, n, ld, cnt, cand, cap, tie_info);
+    return (int)hipGetLastError();
+}
+extern "C" int hdb_launch_finalize(const unsigned long long* cand, const uint32_t* cnt, uint32_t cap, int nq, uint32_t k,
+                                   uint32_t kk, int64_t row_base, int64_t* idx_out, float* score_out, int32_t* status,
+                                   const int* qnan, void* stream) {
+    hipLaunchKernelGGL(hdb_finalize_kernel, dim3(nq), dim3(1024), (size_t)HDB_CAND_CAP * 8, (hipStream_t)stream, cand, cnt, cap, k, kk,
+                       row_base, idx_out, score_out, status, qnan);
+    return (int)hipGetLastError();
+}
+extern "C" int hdb_launch_merge(const void* idx_base, int64_t idx_stride, const void* score_base, int64_t score_stride,
+                                const void* status_base, int64_t status_stride, int parts, int nq, uint32_t k,
+                                int64_t* idx_out, float* score_out, int32_t* status_out, void* stream) {
+    size_t P = 64;
+    while (P < (size_t)parts * k) P <<= 1;
+    hipLaunchKernelGGL(hdb_merge_kernel, dim3(nq), dim3(1024), P * 8, (hipStream_t)stream, (const char*)idx_base, idx_stride,
+                       (const char*)score_base, score_stride, (const char*)status_base, status_stride, parts, nq, k, idx_out,
+                       score_out, status_out);
+    return (int)hipGetLastError();
+}

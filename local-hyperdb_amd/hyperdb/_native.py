@@ -1,0 +1,390 @@
+"""ctypes binding of libhyperdb_hip.so (include/hyperdb_hip.h) + the resident-matrix handle.
+
+This is the only place where Python touches the C ABI.  PyTorch-ROCm is used for device memory,
+streams and H2D/D2H copies only; every score and every top-k comes out of the hand-written HIP
+kernels.  There is no CPU fallback: if the library is missing, importing this module raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+import numpy as np
+import torch  # must be imported before the .so so that ONE libamdhip64 (torch's) serves both
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libhyperdb_hip.so")
+
+HDB_F16, HDB_F32, HDB_F64 = 0, 1, 2
+METRIC_IDS = {
+    "dot_product": 0,
+    "cosine_similarity": 1,
+    "euclidean_metric": 2,
+    "hamming_distance": 3,
+    "manhattan_distance": 4,
+    "jaccard_similarity": 5,
+    "pearson_correlation": 6,
+}
+EUCLIDEAN_DIST = 7
+Q_UNDERFLOW, Q_OVERFLOW, Q_NAN = 1, 2, 4
+HDB_MAX_K = 2048
+
+NAN_MESSAGE = "Vectors and query_vector should not contain NaN values."   # reference ranking_algorithm.py:151
+
+EXPORTS = (
+    "hdb_version", "hdb_last_error", "hdb_index_create", "hdb_index_update", "hdb_index_destroy",
+    "hdb_index_has_nan", "hdb_index_set_bias", "hdb_index_set_row_mask", "hdb_scores", "hdb_topk",
+    "hdb_topk_exact", "hdb_merge_topk", "hdb_set_option", "hdb_get_stat", "hdb_recency_bias",
+    "hdb_packed_bytes", "hdb_merge_topk_packed",
+)
+
+
+class HyperDBNativeError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the MI355X HIP extension has not been built. "
+            "Run `python __graft_entry__.py` (or local-hyperdb_amd/csrc/build.sh). "
+            "There is deliberately no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, cp = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_char_p
+    lib.hdb_version.restype = ctypes.c_int
+    lib.hdb_last_error.restype = cp
+    lib.hdb_index_create.argtypes = [ctypes.POINTER(vp), vp, i64, i32, ctypes.c_int, ctypes.c_int, i64, vp]
+    lib.hdb_index_update.argtypes = [vp, vp, i64, vp]
+    lib.hdb_index_destroy.argtypes = [vp]
+    lib.hdb_index_destroy.restype = None
+    lib.hdb_index_has_nan.argtypes = [vp, ctypes.POINTER(ctypes.c_int)]
+    lib.hdb_index_set_bias.argtypes = [vp, vp]
+    lib.hdb_index_set_row_mask.argtypes = [vp, vp]
+    lib.hdb_scores.argtypes = [vp, vp, ctypes.c_int, vp, vp]
+    lib.hdb_topk.argtypes = [vp, vp, i32, i32, ctypes.c_int, vp, vp, vp, vp]
+    lib.hdb_topk_exact.argtypes = [vp, vp, i32, i32, ctypes.c_int, vp, vp, vp, vp]
+    lib.hdb_merge_topk.argtypes = [vp, vp, i32, i32, i32, vp, vp, ctypes.c_int, vp]
+    lib.hdb_set_option.argtypes = [vp, cp, i64]
+    lib.hdb_get_stat.argtypes = [vp, cp, ctypes.POINTER(i64)]
+    lib.hdb_recency_bias.argtypes = [vp, i64, ctypes.c_double, ctypes.c_double, vp, ctypes.c_int, vp]
+    lib.hdb_packed_bytes.argtypes = [i32, i32]
+    lib.hdb_merge_topk_packed.argtypes = [vp, i32, i32, i32, vp, vp, vp, ctypes.c_int, vp]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name not in ("hdb_last_error", "hdb_index_destroy", "hdb_packed_bytes"):
+            fn.restype = ctypes.c_int
+    lib.hdb_packed_bytes.restype = i64
+    return lib
+
+
+_lib = _load()
+_lock = threading.Lock()
+
+
+def lib():
+    return _lib
+
+
+def _check(rc, what):
+    if rc == 0:
+        return
+    msg = _lib.hdb_last_error().decode("utf-8", "replace")
+    if rc == -1:
+        raise ValueError(f"{what}: {msg}")
+    if rc == -3:
+        raise NotImplementedError(f"{what}: {msg}")
+    raise HyperDBNativeError(f"{what}: {msg} (status {rc})")
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise HyperDBNativeError(
+            "no MI355X visible: the HyperDB ranking path runs only on the GPU (no CPU fallback).")
+
+
+_NP2HDB = {np.dtype(np.float16): HDB_F16, np.dtype(np.float32): HDB_F32, np.dtype(np.float64): HDB_F64}
+_TORCH2HDB = {torch.float16: HDB_F16, torch.float32: HDB_F32, torch.float64: HDB_F64}
+_NP2TORCH = {np.dtype(np.float16): torch.float16, np.dtype(np.float32): torch.float32,
+             np.dtype(np.float64): torch.float64}
+
+
+def _stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def to_device_matrix(vectors, device):
+    """numpy / list / torch -> C-contiguous 2-D torch tensor on `device` in a supported dtype.
+
+    Dtype policy mirrors HyperDB.fp_precision (hyperdb.py:65-66): float16/32/64 stay as they are,
+    anything else numeric (ints, bools) is widened to float64 like numpy would promote it."""
+    if isinstance(vectors, torch.Tensor):
+        t = vectors
+        if t.dtype not in _TORCH2HDB:
+            t = t.to(torch.float64)
+        return t.to(device).contiguous()
+    arr = np.asarray(vectors)
+    if arr.dtype not in _NP2HDB:
+        if not (np.issubdtype(arr.dtype, np.number) or arr.dtype == np.bool_):
+            raise ValueError("vectors must be numeric")
+        arr = arr.astype(np.float64)
+    arr = np.ascontiguousarray(arr)
+    return torch.from_numpy(arr).to(device, non_blocking=False)
+
+
+class GpuIndex:
+    """A resident N x d matrix on one MI355X plus its per-row caches (hdb_index handle).
+
+    Replaces the per-query work of reference ranking_algorithm.py:150 (NaN scan), :153 (copy) and
+    :37 (re-normalising every row): those happen once here, at registration.
+    """
+
+    def __init__(self, vectors, device=None, row_base=0):
+        require_gpu()
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        t = to_device_matrix(vectors, self.device)
+        if t.dim() != 2:
+            # reference: non-2-D vectors make the metric functions raise (tests/test_ranking_algorithm.py:107-114)
+            raise ValueError(f"vectors must be 2-D (N x d), got shape {tuple(t.shape)}")
+        self.V = t
+        self.n, self.d = int(t.shape[0]), int(t.shape[1])
+        if self.d == 0:
+            raise ValueError("vectors must have d > 0")
+        self.dtype = _TORCH2HDB[t.dtype]
+        self.row_base = int(row_base)
+        self._h = ctypes.c_void_p()
+        self._bias = None
+        self._mask = None
+        self._nan = None
+        with torch.cuda.device(self.device):
+            _check(_lib.hdb_index_create(ctypes.byref(self._h), ctypes.c_void_p(t.data_ptr()), self.n, self.d,
+                                         self.dtype, self.device.index or 0, self.row_base,
+                                         _stream_ptr(self.device)), "hdb_index_create")
+
+    # -- lifecycle ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.hdb_index_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def update(self, vectors):
+        """Point the handle at a new matrix (after add/remove) and rebuild the row caches."""
+        t = to_device_matrix(vectors, self.device)
+        if t.dim() != 2 or int(t.shape[1]) != self.d or _TORCH2HDB[t.dtype] != self.dtype:
+            raise ValueError("update: matrix must keep d and dtype")
+        self.V, self.n = t, int(t.shape[0])
+        self._bias = self._mask = self._nan = None
+        _check(_lib.hdb_index_update(self._h, ctypes.c_void_p(t.data_ptr()), self.n, _stream_ptr(self.device)),
+               "hdb_index_update")
+
+    @property
+    def has_nan(self):
+        if self._nan is None:
+            flag = ctypes.c_int(0)
+            _check(_lib.hdb_index_has_nan(self._h, ctypes.byref(flag)), "hdb_index_has_nan")
+            self._nan = bool(flag.value)
+        return self._nan
+
+    # -- per-row additive term / row subset ----------------------------------------------------
+    def set_bias(self, bias):
+        """bias: None, or N floats (numpy / torch) added to every score before top-k."""
+        if bias is None:
+            self._bias = None
+            _check(_lib.hdb_index_set_bias(self._h, None), "hdb_index_set_bias")
+            return
+        if isinstance(bias, torch.Tensor):
+            b = bias.to(self.device, torch.float32).contiguous()
+        else:
+            b = torch.from_numpy(np.ascontiguousarray(np.asarray(bias, dtype=np.float32))).to(self.device)
+        if b.numel() != self.n:
+            raise ValueError(f"bias must have {self.n} entries, got {b.numel()}")
+        self._bias = b
+        _check(_lib.hdb_index_set_bias(self._h, ctypes.c_void_p(b.data_ptr())), "hdb_index_set_bias")
+
+    def set_recency(self, timestamps, recency_bias):
+        """bias = recency_bias * exp(ts - max ts) (reference ranking_algorithm.py:183), computed on the
+        device in float64 from float64 timestamps, stored as float32."""
+        if timestamps is None or len(timestamps) == 0:
+            self.set_bias(None)
+            return
+        if isinstance(timestamps, torch.Tensor):
+            ts = timestamps.to(self.device, torch.float64).contiguous()
+            ts_max = float(ts.max().item())
+        else:
+            ts_h = np.ascontiguousarray(np.asarray(timestamps, dtype=np.float64))
+            ts_max = float(np.max(ts_h))
+            ts = torch.from_numpy(ts_h).to(self.device)
+        if ts.numel() != self.n:
+            raise ValueError(f"operands could not be broadcast together with shapes ({self.n},) ({ts.numel()},)")
+        out = torch.empty(self.n, dtype=torch.float32, device=self.device)
+        _check(_lib.hdb_recency_bias(ctypes.c_void_p(ts.data_ptr()), self.n, float(recency_bias), ts_max,
+                                     ctypes.c_void_p(out.data_ptr()), self.device.index or 0,
+                                     _stream_ptr(self.device)), "hdb_recency_bias")
+        self._bias = out
+        _check(_lib.hdb_index_set_bias(self._h, ctypes.c_void_p(out.data_ptr())), "hdb_index_set_bias")
+
+    def set_row_mask(self, mask):
+        if mask is None:
+            self._mask = None
+            _check(_lib.hdb_index_set_row_mask(self._h, None), "hdb_index_set_row_mask")
+            return
+        if isinstance(mask, torch.Tensor):
+            m = (mask != 0).to(self.device, torch.uint8).contiguous()
+        else:
+            m = torch.from_numpy(np.ascontiguousarray((np.asarray(mask) != 0).astype(np.uint8))).to(self.device)
+        if m.numel() != self.n:
+            raise ValueError("mask must have one entry per row")
+        self._mask = m
+        _check(_lib.hdb_index_set_row_mask(self._h, ctypes.c_void_p(m.data_ptr())), "hdb_index_set_row_mask")
+
+    # -- options / stats -----------------------------------------------------------------------
+    def set_option(self, name, value):
+        _check(_lib.hdb_set_option(self._h, name.encode(), int(value)), "hdb_set_option")
+
+    def stat(self, name):
+        v = ctypes.c_int64(0)
+        _check(_lib.hdb_get_stat(self._h, name.encode(), ctypes.byref(v)), "hdb_get_stat")
+        return int(v.value)
+
+    # -- queries -------------------------------------------------------------------------------
+    def _query_tensor(self, q, batched):
+        qdt = torch.float64 if self.dtype == HDB_F64 else torch.float32
+        if isinstance(q, torch.Tensor):
+            t = q.to(self.device, qdt)
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(np.asarray(q, dtype=np.float64))).to(self.device, qdt)
+        if batched:
+            if t.dim() == 1:
+                t = t.reshape(1, -1)
+            if t.dim() != 2 or t.shape[1] != self.d:
+                raise ValueError(f"shapes ({self.n},{self.d}) and {tuple(t.shape)} not aligned")
+        else:
+            t = t.reshape(-1)
+            if t.numel() != self.d:
+                raise ValueError(f"shapes ({self.n},{self.d}) and ({t.numel()},) not aligned: "
+                                 f"{self.d} (dim 1) != {t.numel()} (dim 0)")
+        return t.contiguous()
+
+    def scores(self, q, metric_id):
+        """All N scores of one query as a float32 CUDA tensor (no bias, no mask)."""
+        qt = self._query_tensor(q, batched=False)
+        out = torch.empty(self.n, dtype=torch.float32, device=self.device)
+        _check(_lib.hdb_scores(self._h, ctypes.c_void_p(qt.data_ptr()), int(metric_id),
+                               ctypes.c_void_p(out.data_ptr()), _stream_ptr(self.device)), "hdb_scores")
+        return out
+
+    def topk_device(self, Q, k, metric_id, exact=False):
+        """Enqueue the top-k of a (nq, d) query batch; returns CUDA tensors (idx, score, status)."""
+        qt = self._query_tensor(Q, batched=True)
+        nq = int(qt.shape[0])
+        idx = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        sc = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+        st = torch.empty((nq,), dtype=torch.int32, device=self.device)
+        fn = _lib.hdb_topk_exact if exact else _lib.hdb_topk
+        _check(fn(self._h, ctypes.c_void_p(qt.data_ptr()), nq, int(k), int(metric_id),
+                  ctypes.c_void_p(idx.data_ptr()), ctypes.c_void_p(sc.data_ptr()),
+                  ctypes.c_void_p(st.data_ptr()), _stream_ptr(self.device)), "hdb_topk")
+        return idx, sc, st
+
+    def topk_packed(self, Q, k, metric_id, record, exact=False):
+        """Enqueue the top-k of a batch straight into a packed exchange record (uint8 CUDA tensor of
+        hdb_packed_bytes(nq, k) bytes): [idx int64][score f32][status i32]."""
+        qt = self._query_tensor(Q, batched=True)
+        nq = int(qt.shape[0])
+        base = record.data_ptr()
+        fn = _lib.hdb_topk_exact if exact else _lib.hdb_topk
+        _check(fn(self._h, ctypes.c_void_p(qt.data_ptr()), nq, int(k), int(metric_id), ctypes.c_void_p(base),
+                  ctypes.c_void_p(base + nq * k * 8), ctypes.c_void_p(base + nq * k * 12),
+                  _stream_ptr(self.device)), "hdb_topk")
+
+    def topk(self, Q, k, metric_id):
+        """Top-k of a query batch on the host: (int64 [nq,k], float32 [nq,k]).  One packed record, one
+        D2H copy.  Queries whose sampled threshold failed (status != 0) are re-run through the exact path."""
+        qt = self._query_tensor(Q, batched=True)
+        nq = int(qt.shape[0])
+        rec = torch.empty(packed_bytes(nq, k), dtype=torch.uint8, device=self.device)
+        self.topk_packed(qt, k, metric_id, rec)
+        idx, sc, st = record_to_host(rec, nq, k)
+        if (st & Q_NAN).any():
+            raise ValueError(NAN_MESSAGE)
+        idx, sc = idx.copy(), sc.copy()
+        bad = np.nonzero(st & (Q_UNDERFLOW | Q_OVERFLOW))[0]
+        if bad.size:
+            sel = torch.from_numpy(bad).to(self.device)
+            qb = qt.index_select(0, sel)
+            rec2 = torch.empty(packed_bytes(int(bad.size), k), dtype=torch.uint8, device=self.device)
+            self.topk_packed(qb, k, metric_id, rec2, exact=True)
+            i2, s2, _ = record_to_host(rec2, int(bad.size), k)
+            idx[bad] = i2
+            sc[bad] = s2
+        return idx, sc
+
+
+def packed_bytes(nq, k):
+    return int(_lib.hdb_packed_bytes(int(nq), int(k)))
+
+
+_pinned = {}
+
+
+def record_to_host(record, nq, k):
+    """ONE D2H copy of a packed record (pinned staging buffer, cached per size) -> numpy views
+    (idx int64 [nq,k], score float32 [nq,k], status int32 [nq]).  Views alias the staging buffer:
+    callers copy what they keep."""
+    nb = record.numel()
+    host = _pinned.get(nb)
+    if host is None:
+        host = torch.empty(nb, dtype=torch.uint8, pin_memory=True)
+        _pinned[nb] = host
+    host.copy_(record, non_blocking=True)
+    torch.cuda.current_stream(record.device).synchronize()
+    h = host.numpy()
+    idx = h[:nq * k * 8].view(np.int64).reshape(nq, k)
+    sc = h[nq * k * 8:nq * k * 12].view(np.float32).reshape(nq, k)
+    st = h[nq * k * 12:nq * k * 12 + nq * 4].view(np.int32)
+    return idx, sc, st
+
+
+def merge_topk_packed_into(gathered, parts, nq, k, out_record):
+    """Merge `parts` gathered records into another packed record (same layout)."""
+    base = out_record.data_ptr()
+    device = gathered.device
+    _check(_lib.hdb_merge_topk_packed(ctypes.c_void_p(gathered.data_ptr()), int(parts), int(nq), int(k),
+                                      ctypes.c_void_p(base), ctypes.c_void_p(base + nq * k * 8),
+                                      ctypes.c_void_p(base + nq * k * 12), device.index or 0, _stream_ptr(device)),
+           "hdb_merge_topk_packed")
+
+
+def merge_topk_packed(gathered, parts, nq, k):
+    """Merge `parts` gathered exchange records (one uint8 CUDA tensor) -> (idx, score, status) CUDA tensors."""
+    device = gathered.device
+    idx = torch.empty((nq, k), dtype=torch.int64, device=device)
+    sc = torch.empty((nq, k), dtype=torch.float32, device=device)
+    st = torch.empty((nq,), dtype=torch.int32, device=device)
+    _check(_lib.hdb_merge_topk_packed(ctypes.c_void_p(gathered.data_ptr()), int(parts), int(nq), int(k),
+                                      ctypes.c_void_p(idx.data_ptr()), ctypes.c_void_p(sc.data_ptr()),
+                                      ctypes.c_void_p(st.data_ptr()), device.index or 0, _stream_ptr(device)),
+           "hdb_merge_topk_packed")
+    return idx, sc, st
+
+
+def merge_topk(idx_parts, score_parts, k):
+    """Merge all-gathered per-shard lists: idx_parts [parts, nq, k] int64, score_parts float32."""
+    parts, nq, kk = (int(x) for x in idx_parts.shape)
+    assert kk == k and score_parts.shape == idx_parts.shape
+    device = idx_parts.device
+    idx = torch.empty((nq, k), dtype=torch.int64, device=device)
+    sc = torch.empty((nq, k), dtype=torch.float32, device=device)
+    ip, sp = idx_parts.contiguous(), score_parts.contiguous()
+    _check(_lib.hdb_merge_topk(ctypes.c_void_p(ip.data_ptr()), ctypes.c_void_p(sp.data_ptr()), parts, nq, k,
+                               ctypes.c_void_p(idx.data_ptr()), ctypes.c_void_p(sc.data_ptr()),
+                               device.index or 0, _stream_ptr(device)), "hdb_merge_topk")
+    return idx, sc

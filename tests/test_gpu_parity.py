@@ -1,0 +1,417 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI via the drop-in shim, against
+
+  * tests/golden/*.npz  -- outputs of the real reference (made by tests/golden/make_golden.py);
+  * oracle/ranking_oracle.py on the same seeded inputs, at sizes the oracle finishes in seconds;
+  * size-independent properties at BASELINE.json's full sizes (fused path == on-device exact path,
+    validity of every returned row against float64-exact scores, shard-merge == global).
+
+Tolerances (BASELINE.json north_star): scores within 1e-3 (fp16 data) / 1e-5 (fp32/fp64 data),
+applied as tol*max(1,|s|); hamming bit-exact.  Index lists must match the reference except for swaps
+inside that band (the fp16 reference rounds its own scores to fp16 -- SURVEY.md section 8a rule 3).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GPU_METRICS = ("dot_product", "cosine_similarity", "euclidean_metric", "hamming_distance")
+
+
+@pytest.fixture(scope="module")
+def ranking():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import hyperdb.ranking_algorithm as r
+    return r
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import ranking_oracle
+    return ranking_oracle
+
+
+def _load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name), allow_pickle=False)
+    return z, json.loads(str(z["manifest"]))
+
+
+def _tol(dtype, metric):
+    if metric == "hamming_distance":
+        return 0.0
+    return 1e-3 if np.dtype(dtype) == np.float16 else 1e-5
+
+
+def _dot_tol(dtype, metric, V=None):
+    # raw dot products of fp32 data: the reference's own sgemv is ~1.6e-5 off exact at |s|~80
+    # (SURVEY.md 8a rule 2) -> relative form already in tol*max(1,|s|); keep 1e-5.
+    return _tol(dtype, metric)
+
+
+# ------------------------------------------------------------------------------------------------
+# 1. the reference's own unit tests, run against the shim (tests/test_ranking_algorithm.py)
+# ------------------------------------------------------------------------------------------------
+class TestReferenceKnownAnswersOnGpu:
+    def test_euclidean_shape_and_values(self, ranking):
+        r = ranking.euclidean_metric(np.array([[1, 2, 3], [4, 5, 6], [7, 8, 9]]), np.array([1, 1, 1]))
+        assert r.shape == (3,) and np.all(r > 0)
+
+    def test_euclidean_empty(self, ranking):
+        with pytest.raises(ValueError):
+            ranking.euclidean_metric(np.array([]), np.array([]))
+
+    def test_cosine_values(self, ranking):
+        r = ranking.cosine_similarity(np.array([[1, 0], [0, 1]]), np.array([1, 0]))
+        assert np.array_equal(r, [1.0, 0.0])
+
+    def test_hamming(self, ranking):
+        r = ranking.hamming_distance(np.array([[1, 1], [0, 1], [1, 0]]), np.array([1, 1]))
+        assert np.array_equal(r, [2, 1, 1])
+
+    @pytest.mark.parametrize("metric, rb, expected", [
+        ("cosine_similarity", 0, [0, 2, 1]), ("cosine_similarity", 1, [2, 0, 1]),
+        ("euclidean_metric", 0, [0, 2, 1]), ("hamming_distance", 0, [0, 2, 1]), ("dot_product", 0, [0, 2, 1])])
+    def test_sort(self, ranking, metric, rb, expected):
+        V = np.array([[1, 0], [0, 1], [0.5, 0.5]])
+        idx, _ = ranking.hyperDB_ranking_algorithm_sort(
+            V, np.array([1, 0]), metric=metric, timestamps=[1627825200.0, 1627911600.0, 1627998000.0], recency_bias=rb)
+        assert list(idx) == expected
+
+    def test_unknown_metric(self, ranking):
+        with pytest.raises(ValueError):
+            ranking.hyperDB_ranking_algorithm_sort(np.array([[1, 0], [0, 1]]), np.array([1, 0]), metric="unknown_metric")
+
+    def test_1d_vectors(self, ranking):
+        with pytest.raises(ValueError):
+            ranking.hyperDB_ranking_algorithm_sort(np.array([1, 0]), np.array([1, 0]), metric="euclidean_metric")
+
+    def test_nan(self, ranking):
+        with pytest.raises(ValueError):
+            ranking.hyperDB_ranking_algorithm_sort(np.array([[1, 0], [0, 1], [np.nan, np.nan]]), np.array([1, 0]))
+        with pytest.raises(ValueError):
+            ranking.hyperDB_ranking_algorithm_sort(np.array([[1.0, 0], [0, 1]]), np.array([np.nan, 0]))
+
+
+# ------------------------------------------------------------------------------------------------
+# 2. golden vectors produced by the real reference
+# ------------------------------------------------------------------------------------------------
+def test_kat_golden_scores(ranking, golden_dir):
+    z, cases = _load(golden_dir, "kat.npz")
+    for c in cases:
+        if c["kind"] != "sort" or c["metric"] not in GPU_METRICS:
+            continue
+        idx, sc = ranking.hyperDB_ranking_algorithm_sort(z["sort.V"].copy(), z["sort.q"].copy(), metric=c["metric"],
+                                                         timestamps=list(z["sort.ts"]), recency_bias=c["recency_bias"])
+        assert idx.dtype == np.int64 and sc.dtype == np.float64
+        assert list(idx) == list(z[c["name"] + ".idx"]), c["name"]
+        assert np.allclose(sc, z[c["name"] + ".scores"], atol=1e-6, rtol=0), c["name"]
+
+
+def test_sweep_golden_topk(ranking, orc, golden_dir):
+    """All (matrix, query, metric, k, recency) cases of sweep.npz for the four GPU metrics."""
+    z, cases = _load(golden_dir, "sweep.npz")
+    handles = {}
+    n_checked = 0
+    for c in cases:
+        if c["metric"] not in GPU_METRICS:
+            continue
+        V, q = z[c["mat"] + ".V"], z[f"{c['mat']}.{c['query']}"]
+        if c["mat"] not in handles:
+            handles[c["mat"]] = ranking.register_vectors(V)
+        ts = {"none": None, "unix": z[c["mat"] + ".ts"], "small": z[c["mat"] + ".ts_small"]}[c["recency"]]
+        idx, sc = ranking.hyperDB_ranking_algorithm_sort(handles[c["mat"]], q.copy(), top_k=c["top_k"], metric=c["metric"],
+                                                         timestamps=ts, recency_bias=c["recency_bias"])
+        ref_idx, ref_sc = z[c["name"] + ".idx"], z[c["name"] + ".scores"]
+        tol = _tol(V.dtype, c["metric"])
+        bias = None if ts is None else c["recency_bias"] * np.exp(ts - np.max(ts))
+        orc.check_topk(idx, sc, V, q, c["metric"], c["top_k"], bias=bias, tol=tol)
+        if c["metric"] == "hamming_distance":
+            # bit-exact score multiset; tie order canonical on our side, arbitrary in the reference
+            assert np.array_equal(np.sort(sc), np.sort(ref_sc)), c["name"]
+        else:
+            assert orc.same_result_modulo_ties(idx, sc, ref_idx, ref_sc, tol), c["name"]
+        n_checked += 1
+    for h in handles.values():
+        h.close()
+    assert n_checked == 4 * 8 * 2 * 4 + 4 * 8 * 2       # metrics x mats x queries x k  + recency cases
+
+
+def test_sweep_golden_full_vectors(ranking, golden_dir):
+    z, cases = _load(golden_dir, "sweep.npz")
+    seen = set()
+    for c in cases:
+        key = (c["mat"], c["query"], c["metric"])
+        if key in seen or c["metric"] not in GPU_METRICS:
+            continue
+        seen.add(key)
+        V, q = z[c["mat"] + ".V"], z[f"{c['mat']}.{c['query']}"]
+        fn = getattr(ranking, c["metric"])
+        got = fn(V, q.copy())
+        want = z[f"{c['mat']}.{c['query']}.{c['metric']}.full"]
+        assert got.shape == want.shape and got.dtype == want.dtype, key
+        if c["metric"] == "hamming_distance":
+            assert np.array_equal(got, want), key
+        else:
+            tol = _tol(V.dtype, c["metric"])
+            g, w = got.astype(np.float64), want.astype(np.float64)
+            assert np.all(np.abs(g - w) <= 2 * tol * np.maximum(1, np.abs(w))), (key, np.abs(g - w).max())
+
+
+def test_edge_golden(ranking, orc, golden_dir, capsys):
+    z, cases = _load(golden_dir, "edge.npz")
+    for c in cases:
+        name = c["name"]
+        if c["metric"] not in GPU_METRICS:
+            continue
+        kw = {k: c[k] for k in ("top_k", "metric", "recency_bias") if k in c}
+        if name + ".ts" in z.files:
+            kw["timestamps"] = z[name + ".ts"]
+        q = z[name + ".q"].copy()
+        V = z[name + ".V"]
+        idx, sc = ranking.hyperDB_ranking_algorithm_sort(V.copy(), q, **kw)
+        printed = capsys.readouterr().out
+        ref_idx, ref_sc = z[name + ".idx"], z[name + ".scores"]
+        assert np.asarray(idx).shape == ref_idx.shape, name
+        assert np.asarray(sc).shape == ref_sc.shape, name          # includes the (1,1) single-row quirk
+        assert printed == c["printed"], name
+        if c["metric"] == "hamming_distance":
+            assert np.array_equal(q, z[name + ".q_after"]), name    # in-place binarisation of the query
+            assert np.array_equal(np.sort(np.asarray(sc).ravel()), np.sort(ref_sc.ravel())), name
+            continue
+        tol = _tol(V.dtype, c["metric"])
+        if len(ref_idx) == 0:
+            continue
+        assert np.allclose(np.asarray(sc, dtype=np.float64).ravel(), ref_sc.ravel(), atol=10 * tol, rtol=0), name
+        if name in ("duplicate_rows", "zero_rows_cosine", "zero_query_cosine"):
+            # exact float ties: reference order arbitrary, ours canonical -> compare score lists + validity
+            orc.check_topk(idx, sc, V, q.reshape(-1), c["metric"], c["top_k"], tol=tol)
+            if name == "duplicate_rows":
+                ci, cs = orc.canonical(idx, sc)
+                assert np.array_equal(ci, np.asarray(idx)), "ties must come out by ascending index"
+        else:
+            assert list(np.asarray(idx).ravel()) == list(ref_idx.ravel()), name
+
+
+# ------------------------------------------------------------------------------------------------
+# 3. oracle on seeded inputs at sizes it finishes in seconds (fused sampled-threshold path, N > 8192)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype,n,d", [(np.float32, 100_000, 384), (np.float16, 120_000, 384),
+                                       (np.float16, 60_000, 768), (np.float64, 30_000, 96),
+                                       (np.float32, 50_000, 100), (np.float16, 40_001, 50)])
+def test_oracle_parity_medium(ranking, orc, dtype, n, d):
+    rng = np.random.default_rng(n + d)
+    V = rng.standard_normal((n, d)).astype(np.float32).astype(dtype)
+    h = ranking.register_vectors(V)
+    try:
+        for metric in GPU_METRICS:
+            for qi in range(2):
+                q = (rng.standard_normal(d) if qi == 0 else V[n // 5].astype(np.float64) + 0.1 * rng.standard_normal(d))
+                q = q.astype(dtype)
+                idx, sc = ranking.hyperDB_ranking_algorithm_sort(h, q.copy(), top_k=100, metric=metric)
+                oi, osc = orc.rank(V, q.copy(), top_k=100, metric=metric)
+                tol = _tol(dtype, metric)
+                orc.check_topk(idx, sc, V, q, metric, 100, tol=tol)
+                if metric == "hamming_distance":
+                    assert np.array_equal(sc, np.sort(osc)[::-1]), (metric, qi)
+                else:
+                    assert orc.same_result_modulo_ties(idx, sc, oi, osc, tol), (metric, qi)
+        assert h.index.stat("path") in (1, 2)
+    finally:
+        h.close()
+
+
+def test_config2_fp32_1m_cosine(ranking, orc):
+    """BASELINE config 2: N=1M d=384 fp32 single-query cosine top-100, against the oracle itself."""
+    n, d = 1_000_000, 384
+    rng = np.random.default_rng(1234)
+    V = np.empty((n, d), dtype=np.float32)
+    for lo in range(0, n, 100_000):
+        V[lo:lo + 100_000] = rng.standard_normal((100_000, d), dtype=np.float32)
+    q = np.random.default_rng(4321).standard_normal(d).astype(np.float32)
+    h = ranking.register_vectors(V)
+    try:
+        idx, sc = ranking.hyperDB_ranking_algorithm_sort(h, q, top_k=100, metric="cosine_similarity")
+        assert h.index.stat("path") == 1                                   # fused sampled-threshold path
+        oi, osc = orc.rank(V, q, top_k=100, metric="cosine_similarity")
+        assert list(idx) == list(oi)
+        assert np.all(np.abs(sc - osc) <= 1e-5)
+        idx2, sc2 = ranking.hyperDB_ranking_algorithm_sort(h, q, top_k=100, metric="euclidean_metric")
+        oi2, osc2 = orc.rank(V, q, top_k=100, metric="euclidean_metric")
+        assert list(idx2) == list(oi2) and np.all(np.abs(sc2 - osc2) <= 1e-5)
+    finally:
+        h.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# 4. properties at full size (N=10M d=384 fp16, top-100): fused == exact on device, validity of
+#    every returned row against float64 scores of those rows, recency, batches
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def big_fp16():
+    import torch
+    n, d, blk = 10_000_000, 384, 250_000
+    V = torch.empty((n, d), dtype=torch.float16, device="cuda")
+    for b in range(n // blk):
+        g = torch.Generator(device="cuda").manual_seed(1234 + b)
+        V[b * blk:(b + 1) * blk] = torch.randn((blk, d), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+    g = torch.Generator(device="cuda").manual_seed(4321)
+    Q = torch.randn((8, d), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+    from hyperdb._native import GpuIndex
+    ix = GpuIndex(V)
+    yield ix, V, Q
+    ix.close()
+
+
+@pytest.mark.parametrize("metric", ["cosine_similarity", "dot_product", "euclidean_metric"])
+def test_full_size_fused_equals_exact(big_fp16, orc, metric):
+    import torch
+    from hyperdb._native import METRIC_IDS
+    ix, V, Q = big_fp16
+    mid = METRIC_IDS[metric]
+    idx, sc, st = ix.topk_device(Q[:4], 100, mid)
+    assert int(st.abs().sum().item()) == 0, "sampled threshold failed on iid data"
+    assert ix.stat("path") == 1
+    eidx, esc, _ = ix.topk_device(Q[:4], 100, mid, exact=True)
+    assert ix.stat("path") == 2
+    assert torch.equal(idx, eidx) and torch.equal(sc, esc)
+    # validity of the returned rows against float64 scores computed on the host from those rows only,
+    # and against a float64 threshold count on a 1M-row slice
+    idx_h, sc_h = idx.cpu().numpy(), sc.cpu().numpy()
+    for qi in range(2):
+        rows = V[idx[qi]].cpu().numpy()
+        ex = orc.exact_scores(rows, Q[qi].cpu().numpy(), metric)
+        assert np.all(np.abs(ex - sc_h[qi]) <= 1e-3 * np.maximum(1, np.abs(ex)))
+        assert np.all(np.diff(sc_h[qi]) <= 0) and np.unique(idx_h[qi]).size == 100
+        sl = V[:1_000_000].cpu().numpy()
+        ex_sl = orc.exact_scores(sl, Q[qi].cpu().numpy(), metric)
+        kth = sc_h[qi][-1]
+        better = np.nonzero(ex_sl > kth + 2e-3 * max(1.0, abs(kth)))[0]
+        assert set(better.tolist()) <= set(idx_h[qi].tolist()), "a clearly better row was left out"
+
+
+def test_full_size_hamming_exact_properties(big_fp16, orc):
+    from hyperdb._native import METRIC_IDS
+    ix, V, Q = big_fp16
+    idx, sc, st = ix.topk_device(Q[:2], 100, METRIC_IDS["hamming_distance"])
+    idx_h, sc_h = idx.cpu().numpy(), sc.cpu().numpy()
+    for qi in range(2):
+        rows = V[idx[qi]].cpu().numpy()
+        ex = orc.exact_scores(rows, Q[qi].cpu().numpy(), "hamming_distance")
+        assert np.array_equal(ex, sc_h[qi].astype(np.float64))              # bit-exact integer scores
+        assert np.all(np.diff(sc_h[qi]) <= 0)
+        # canonical tie order: equal scores by ascending index
+        for s in np.unique(sc_h[qi]):
+            run = idx_h[qi][sc_h[qi] == s]
+            assert np.all(np.diff(run) > 0)
+        # boundary: on the first 2M rows no row beats the k-th score unless returned, and ties at the
+        # boundary are the lowest-indexed ones
+        sl = V[:2_000_000].cpu().numpy()
+        ex_sl = orc.exact_scores(sl, Q[qi].cpu().numpy(), "hamming_distance")
+        kth = sc_h[qi][-1]
+        assert set(np.nonzero(ex_sl > kth)[0].tolist()) <= set(idx_h[qi].tolist())
+
+
+def test_full_size_batch_equals_singles(big_fp16):
+    import torch
+    from hyperdb._native import METRIC_IDS
+    ix, V, Q = big_fp16
+    mid = METRIC_IDS["dot_product"]
+    bi, bs, st = ix.topk_device(Q, 100, mid)
+    assert int(st.abs().sum().item()) == 0
+    for qi in (0, 5, 7):
+        si, ss, _ = ix.topk_device(Q[qi:qi + 1], 100, mid)
+        assert torch.equal(si[0], bi[qi])
+        assert torch.allclose(ss[0], bs[qi], rtol=1e-6, atol=1e-6)
+
+
+def test_full_size_recency_and_mask(big_fp16, orc):
+    import torch
+    from hyperdb._native import METRIC_IDS
+    ix, V, Q = big_fp16
+    n = ix.n
+    g = torch.Generator(device="cuda").manual_seed(99)
+    ts = 1.7e9 + torch.rand(n, generator=g, device="cuda", dtype=torch.float64) * 30 * 86400.0
+    ix.set_recency(ts, 0.5)
+    try:
+        mid = METRIC_IDS["cosine_similarity"]
+        idx, sc, st = ix.topk_device(Q[:1], 100, mid)
+        eidx, esc, _ = ix.topk_device(Q[:1], 100, mid, exact=True)
+        assert torch.equal(idx, eidx) and torch.equal(sc, esc)
+        # the newest documents must dominate: bias up to 0.5 vs cosine ~ +-0.2
+        ts_h = ts[idx[0]].cpu().numpy()
+        bias = 0.5 * np.exp(ts_h - float(ts.max().item()))
+        rows = V[idx[0]].cpu().numpy()
+        ex = orc.exact_scores(rows, Q[0].cpu().numpy(), "cosine_similarity") + bias
+        assert np.all(np.abs(ex - sc[0].cpu().numpy()) <= 1e-3)
+    finally:
+        ix.set_bias(None)
+    mask = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    mask[::7] = 1
+    ix.set_row_mask(mask)
+    try:
+        idx, sc, st = ix.topk_device(Q[:1], 50, METRIC_IDS["dot_product"])
+        if int(st[0].item()) != 0:
+            idx, sc, _ = ix.topk_device(Q[:1], 50, METRIC_IDS["dot_product"], exact=True)
+        assert torch.all(idx[0] % 7 == 0)
+    finally:
+        ix.set_row_mask(None)
+
+
+# ------------------------------------------------------------------------------------------------
+# 5. exact path: heavy ties, forced overflow fallback, merge of shards
+# ------------------------------------------------------------------------------------------------
+def test_massive_float_ties_and_fallback(ranking, orc):
+    rng = np.random.default_rng(5)
+    base = rng.standard_normal((50, 64)).astype(np.float32)
+    V = np.tile(base, (2000, 1))                       # 100k rows, every score value repeated 2000 times
+    q = rng.standard_normal(64).astype(np.float32)
+    h = ranking.register_vectors(V)
+    try:
+        idx, sc = ranking.hyperDB_ranking_algorithm_sort(h, q, top_k=100, metric="dot_product")
+        ex = orc.exact_scores(V, q, "dot_product")
+        best = np.max(ex)
+        assert np.allclose(sc, best, rtol=1e-5)         # top-100 all tie at the best score
+        want = np.nonzero(np.isclose(ex, best, rtol=1e-6))[0][:100]
+        assert np.array_equal(idx, want), "ties must resolve to the lowest row indices"
+    finally:
+        h.close()
+
+
+def test_shard_merge_equals_global(orc):
+    import torch
+    from hyperdb._native import GpuIndex, METRIC_IDS, merge_topk, merge_topk_packed, packed_bytes
+    rng = np.random.default_rng(11)
+    n, d, k, parts = 90_000, 128, 100, 3
+    V = rng.standard_normal((n, d)).astype(np.float32).astype(np.float16)
+    Q = rng.standard_normal((5, d)).astype(np.float16)
+    mid = METRIC_IDS["cosine_similarity"]
+    whole = GpuIndex(V)
+    gi, gs, _ = whole.topk_device(Q, k, mid)
+    per = n // parts
+    shards = [GpuIndex(V[p * per:(p + 1) * per], row_base=p * per) for p in range(parts)]
+    outs = [s.topk_device(Q, k, mid) for s in shards]
+    mi, ms = merge_topk(torch.stack([o[0] for o in outs]), torch.stack([o[1] for o in outs]), k)
+    assert torch.equal(mi, gi) and torch.equal(ms, gs)
+    nb = packed_bytes(5, k)
+    rec = torch.zeros((parts, nb), dtype=torch.uint8, device="cuda")
+    for p, s in enumerate(shards):
+        s.topk_packed(Q, k, mid, rec[p])
+    pi, ps, pst = merge_topk_packed(rec, parts, 5, k)
+    assert torch.equal(pi, gi) and torch.equal(ps, gs) and int(pst.abs().sum().item()) == 0
+    for s in shards + [whole]:
+        s.close()
+
+
+def test_rank_batch_matches_oracle(ranking, orc):
+    rng = np.random.default_rng(21)
+    V = rng.standard_normal((30_000, 384)).astype(np.float32).astype(np.float16)
+    Q = rng.standard_normal((37, 384)).astype(np.float16)
+    idx, sc = ranking.rank_batch(V, Q, top_k=20, metric="dot_product")
+    assert idx.shape == (37, 20) and sc.dtype == np.float64
+    for qi in (0, 17, 36):
+        oi, osc = orc.rank(V, Q[qi], top_k=20, metric="dot_product")
+        assert orc.same_result_modulo_ties(idx[qi], sc[qi], oi, osc, 1e-3)
+        orc.check_topk(idx[qi], sc[qi], V, Q[qi], "dot_product", 20, tol=1e-3)
