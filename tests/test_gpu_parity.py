@@ -127,8 +127,10 @@ def test_sweep_golden_topk(ranking, orc, golden_dir):
         ref_idx, ref_sc = z[c["name"] + ".idx"], z[c["name"] + ".scores"]
         tol = _tol(V.dtype, c["metric"])
         bias = None if ts is None else c["recency_bias"] * np.exp(ts - np.max(ts))
+        if bias is not None:
+            tol = max(tol, 1e-5)        # the recency term is a float32 on the device (integer scores stop being integers)
         orc.check_topk(idx, sc, V, q, c["metric"], c["top_k"], bias=bias, tol=tol)
-        if c["metric"] == "hamming_distance":
+        if c["metric"] == "hamming_distance" and bias is None:
             # bit-exact score multiset; tie order canonical on our side, arbitrary in the reference
             assert np.array_equal(np.sort(sc), np.sort(ref_sc)), c["name"]
         else:
