@@ -38,6 +38,7 @@ int hdb_launch_merge(const void* idx_base, int64_t idx_stride, const void* score
                      float* score_out, int32_t* status_out, void* stream);
 int hdb_launch_recency(const double* ts, int64_t n, double rb, double ts_max, float* out, void* stream);
 int hdb_mfma_supported(int dtype, int d, int metric);
+int hdb_mfma_tile_rows(int d);
 int hdb_launch_mfma_scan(const ScanArgs* args, int mode, int nq_launch, const void* q16, const float* sqnorm,
                          const float* qsq, int max_blocks, void* stream);
 int hdb_launch_q_to_f16(const float* Q, int nq, int d, void* q16, void* stream);
@@ -89,7 +90,7 @@ struct hdb_index {
     int64_t use_mfma = 1;
     int64_t exact_bytes = (int64_t)1 << 30;
     // stats of the last hdb_topk call
-    int64_t st_sample_rows = 0, st_sample_m = 0, st_path = 0, st_chunks = 0;
+    int64_t st_sample_rows = 0, st_sample_m = 0, st_path = 0, st_chunks = 0, st_mfma = 0;
     // optional HIP-event timing of the dominant kernel (the pass over all of V)
     int64_t profile = 0;
     std::vector<hipEvent_t> ev_pool;      // pairs: [2i] start, [2i+1] stop
@@ -219,6 +220,7 @@ extern "C" int hdb_get_stat(hdb_index* ix, const char* name, int64_t* value) {
     else if (!strcmp(name, "sample_m")) *value = ix->st_sample_m;
     else if (!strcmp(name, "path")) *value = ix->st_path;
     else if (!strcmp(name, "chunks")) *value = ix->st_chunks;
+    else if (!strcmp(name, "mfma")) *value = ix->st_mfma;
     else if (!strcmp(name, "cand_cap")) *value = HDB_CAND_CAP;
     else if (!strcmp(name, "n")) *value = ix->n;
     else if (!strcmp(name, "ws_bytes")) *value = (int64_t)ix->ws_bytes;
@@ -320,13 +322,17 @@ extern "C" int hdb_scores(hdb_index* ix, const void* dev_q, int metric, float* d
     return run_scan(ix, a, 0, 1, qb, false, st);
 }
 
-static void sample_plan(const hdb_index* ix, uint32_t kk, int64_t& tiles, int64_t& stride, uint32_t& m) {
+// Row sample for the threshold estimate: `tiles` tiles of `tile_rows` rows, evenly strided over V.
+// The m-th largest of the sampled scores is exceeded by about T rows of the full matrix (Gamma(m)
+// spread), T >= 8k..16k and <= CAP/2, so both "fewer than k pass" and "more than CAP pass" are
+// < 1e-9 events for exchangeable row orders; either one only costs the exact-path re-run.
+static void sample_plan(const hdb_index* ix, uint32_t kk, int tile_rows, int64_t& tiles, int64_t& stride, uint32_t& m) {
     int64_t T = ix->sample_target > 0 ? ix->sample_target : (kk <= 128 ? 2048 : 4096);
     m = kk <= 128 ? 16u : (kk <= 512 ? 64u : 256u);
     int64_t rows = (int64_t)((double)m * (double)ix->n / (double)T);
     rows = std::max<int64_t>(rows, 16 * (int64_t)m);         // at least 16 m sample rows
-    tiles = (rows + 15) / 16;
-    const int64_t all_tiles = ix->n / 16;                    // full tiles only: sample rows always exist
+    tiles = (rows + tile_rows - 1) / tile_rows;
+    const int64_t all_tiles = ix->n / tile_rows;             // full tiles only: sample rows always exist
     tiles = std::min(tiles, all_tiles);
     stride = std::max<int64_t>(1, all_tiles / std::max<int64_t>(tiles, 1));
 }
@@ -357,12 +363,14 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     const bool is_ham = metric == HDB_HAMMING;
     if (is_ham && !small) exact = true;                      // integer scores: massive ties by construction
     if (ix->force_exact && !small) exact = true;
-    const bool mfma_ok = ix->use_mfma && !is_ham && hdb_mfma_supported(ix->dtype, ix->d, metric);
+    const bool mfma = ix->use_mfma && !is_ham && !small && !ix->mask && nq >= ix->mfma_min_q &&
+                      hdb_mfma_supported(ix->dtype, ix->d, metric);
+    const int tile_rows = mfma ? hdb_mfma_tile_rows(ix->d) : 16;
 
     // ---- plan the chunking --------------------------------------------------------------------
     int64_t s_tiles = 0, s_stride = 1; uint32_t m = 0;
-    if (!small && !exact) sample_plan(ix, kk, s_tiles, s_stride, m);
-    const int64_t s_rows = s_tiles * 16;
+    if (!small && !exact) sample_plan(ix, kk, tile_rows, s_tiles, s_stride, m);
+    const int64_t s_rows = s_tiles * tile_rows;
     const int64_t ld_s = align_up((size_t)std::max<int64_t>(s_rows, 4), 4);
     const int64_t ld_n = align_up((size_t)n, 4);
     int cq_max = 256;
@@ -398,16 +406,17 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     bool q16_ready = false;
     ix->st_sample_rows = s_rows; ix->st_sample_m = m; ix->st_chunks = 0;
     ix->st_path = small ? 0 : (exact ? 2 : 1);
+    ix->st_mfma = mfma ? 1 : 0;
 
     for (int q0 = 0; q0 < nq; q0 += cq_max) {
         const int cq = std::min(cq_max, nq - q0);
         ix->st_chunks++;
-        const bool mfma = mfma_ok && cq >= ix->mfma_min_q;
         if (mfma && !q16_ready) { LAUNCH_TRY(hdb_launch_q_to_f16((const float*)dev_Q, nq, ix->d, q16, st)); q16_ready = true; }
         QueryBufs qb{qinv, qsq, qbits, q16};
         ScanArgs a; base_args(ix, a, dev_Q, metric);
         a.q0 = q0; a.bias = ix->bias;
         a.thr = thr; a.cnt = cnt; a.cand = cand;
+        a.ntiles = (n + tile_rows - 1) / tile_rows;
 
         if (small) {
             LAUNCH_TRY(hdb_launch_fill_thr(thr, cnt, cq, -INFINITY, st));

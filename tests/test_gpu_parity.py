@@ -417,3 +417,69 @@ def test_rank_batch_matches_oracle(ranking, orc):
         oi, osc = orc.rank(V, Q[qi], top_k=20, metric="dot_product")
         assert orc.same_result_modulo_ties(idx[qi], sc[qi], oi, osc, 1e-3)
         orc.check_topk(idx[qi], sc[qi], V, Q[qi], "dot_product", 20, tol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------
+# 6. MFMA batched path (fp16, d=384): same answers as the VALU scan and as the oracle
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("metric", ["dot_product", "cosine_similarity"])
+@pytest.mark.parametrize("nq", [256, 100, 8, 300])
+def test_mfma_batch_matches_valu_and_oracle(orc, metric, nq):
+    import torch
+    from hyperdb._native import GpuIndex, METRIC_IDS
+    rng = np.random.default_rng(nq)
+    n, d, k = 200_003, 384, 100                       # ragged last tile on purpose
+    V = rng.standard_normal((n, d)).astype(np.float32).astype(np.float16)
+    Q = rng.standard_normal((nq, d)).astype(np.float16)
+    Q[1] = V[n - 1]                                   # exact duplicate of the very last row
+    Q[2] = V[777] * 0.5
+    ix = GpuIndex(V)
+    try:
+        mid = METRIC_IDS[metric]
+        mi, ms, mst = ix.topk_device(Q, k, mid)
+        assert ix.stat("mfma") == 1 and ix.stat("path") == 1
+        assert int(mst.abs().sum().item()) == 0
+        ix.set_option("use_mfma", 0)
+        vi, vs, vst = ix.topk_device(Q, k, mid)
+        assert ix.stat("mfma") == 0
+        ix.set_option("use_mfma", 1)
+        mi_h, ms_h, vi_h, vs_h = mi.cpu().numpy(), ms.cpu().numpy(), vi.cpu().numpy(), vs.cpu().numpy()
+        # both paths accumulate exact fp16 products in fp32, in different orders: scores agree to ~1e-5 rel
+        assert np.all(np.abs(ms_h - vs_h) <= 2e-5 * np.maximum(1, np.abs(vs_h)))
+        for qi in range(nq):
+            assert orc.same_result_modulo_ties(mi_h[qi], ms_h[qi], vi_h[qi], vs_h[qi], 2e-5), qi
+        assert mi_h[1][0] == n - 1 and mi_h[2][0] == 777
+        for qi in (0, 1, nq - 1):
+            orc.check_topk(mi_h[qi], ms_h[qi], V, Q[qi], metric, k, tol=1e-3)
+            oi, osc = orc.rank(V, Q[qi].copy(), top_k=k, metric=metric)
+            assert orc.same_result_modulo_ties(mi_h[qi], ms_h[qi], oi, osc, 1e-3), qi
+        # exact path through the MFMA score writer
+        ei, es, _ = ix.topk_device(Q[:16], k, mid, exact=True)
+        assert ix.stat("mfma") == 1 and ix.stat("path") == 2
+        assert torch.equal(ei, mi[:16]) and torch.equal(es, ms[:16])
+    finally:
+        ix.close()
+
+
+def test_mfma_with_recency_bias(orc):
+    import torch
+    from hyperdb._native import GpuIndex, METRIC_IDS
+    rng = np.random.default_rng(3)
+    n, d, k, nq = 150_000, 384, 50, 64
+    V = rng.standard_normal((n, d)).astype(np.float32).astype(np.float16)
+    Q = rng.standard_normal((nq, d)).astype(np.float16)
+    ts = 1.7e9 + rng.uniform(0, 86400.0 * 3, size=n)
+    ix = GpuIndex(V)
+    try:
+        ix.set_recency(ts, 0.75)
+        mid = METRIC_IDS["cosine_similarity"]
+        mi, ms, mst = ix.topk_device(Q, k, mid)
+        assert ix.stat("mfma") == 1 and int(mst.abs().sum().item()) == 0
+        ix.set_option("use_mfma", 0)
+        vi, vs, _ = ix.topk_device(Q, k, mid)
+        assert torch.equal(mi, vi)
+        assert torch.allclose(ms, vs, rtol=2e-5, atol=2e-5)
+        bias = 0.75 * np.exp(ts - ts.max())
+        orc.check_topk(mi[0].cpu().numpy(), ms[0].cpu().numpy(), V, Q[0], "cosine_similarity", k, bias=bias, tol=1e-3)
+    finally:
+        ix.close()
