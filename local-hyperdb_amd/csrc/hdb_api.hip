@@ -29,6 +29,7 @@ int hdb_launch_hamming(const ScanArgs* args, int mode, int nq_launch, const uint
 int hdb_launch_hist(const float* scores, int64_t n, int64_t ld, int nq, uint32_t* hist, int pass, uint32_t k, void* stream);
 int hdb_launch_thr(const uint32_t* hist, int nq, int npass, uint32_t m, uint32_t sample_n, float* thr, uint32_t* cnt, void* stream);
 int hdb_launch_fill_thr(float* thr, uint32_t* cnt, int nq, float v, void* stream);
+int hdb_launch_sample_thr(const float* scores, int64_t n, int64_t ld, int nq, uint32_t m, float* thr, uint32_t* cnt, void* stream);
 int hdb_launch_collect(const float* scores, int64_t n, int64_t ld, int nq, const uint32_t* hist, uint32_t k, uint32_t* cnt,
                        unsigned long long* cand, uint32_t cap, uint32_t* tie_info, void* stream);
 int hdb_launch_finalize(const unsigned long long* cand, const uint32_t* cnt, uint32_t cap, int nq, uint32_t k, uint32_t kk,
@@ -89,6 +90,8 @@ struct hdb_index {
     int64_t mfma_min_q = 8;
     int64_t use_mfma = 1;
     int64_t exact_bytes = (int64_t)1 << 30;
+    int64_t debug_flags = 0;
+    void* dbg_buf = nullptr;
     // stats of the last hdb_topk call
     int64_t st_sample_rows = 0, st_sample_m = 0, st_path = 0, st_chunks = 0, st_mfma = 0;
     // optional HIP-event timing of the dominant kernel (the pass over all of V)
@@ -209,6 +212,7 @@ extern "C" int hdb_set_option(hdb_index* ix, const char* name, int64_t value) {
     else if (!strcmp(name, "mfma_min_q")) ix->mfma_min_q = value;
     else if (!strcmp(name, "use_mfma")) ix->use_mfma = value;
     else if (!strcmp(name, "exact_bytes")) ix->exact_bytes = std::max<int64_t>(1 << 20, value);
+    else if (!strcmp(name, "debug_flags")) ix->debug_flags = value;
     else if (!strcmp(name, "profile")) { ix->profile = value; ix->ev_used = 0; }
     else return fail(HDB_ERR_ARG, std::string("hdb_set_option: unknown option ") + name);
     return HDB_OK;
@@ -225,6 +229,7 @@ extern "C" int hdb_get_stat(hdb_index* ix, const char* name, int64_t* value) {
     else if (!strcmp(name, "n")) *value = ix->n;
     else if (!strcmp(name, "ws_bytes")) *value = (int64_t)ix->ws_bytes;
     else if (!strcmp(name, "scan_launches")) *value = (int64_t)(ix->ev_used / 2);
+    else if (!strcmp(name, "debug_buffer")) *value = (int64_t)(uintptr_t)ix->dbg_buf;
     else if (!strcmp(name, "scan_time_ns")) {      // sum over recorded launches; synchronises on the last event
         double total_ms = 0.0;
         for (size_t i = 0; i + 1 < ix->ev_used; i += 2) {
@@ -282,6 +287,7 @@ static void base_args(const hdb_index* ix, ScanArgs& a, const void* Q, int metri
     a.inv_norm = ix->inv_norm; a.mask = ix->mask;
     a.tile_stride = 1; a.ntiles = (ix->n + 15) / 16;
     a.cap = HDB_CAND_CAP;
+    a.dbg = (int32_t)ix->debug_flags;
 }
 
 // One scan launch (VALU, hamming or MFMA flavour) for queries [a.q0, a.q0+cq).
@@ -328,7 +334,7 @@ extern "C" int hdb_scores(hdb_index* ix, const void* dev_q, int metric, float* d
 // < 1e-9 events for exchangeable row orders; either one only costs the exact-path re-run.
 static void sample_plan(const hdb_index* ix, uint32_t kk, int tile_rows, int64_t& tiles, int64_t& stride, uint32_t& m) {
     int64_t T = ix->sample_target > 0 ? ix->sample_target : (kk <= 128 ? 2048 : 4096);
-    m = kk <= 128 ? 16u : (kk <= 512 ? 64u : 256u);
+    m = kk <= 128 ? 8u : (kk <= 512 ? 64u : 256u);
     int64_t rows = (int64_t)((double)m * (double)ix->n / (double)T);
     rows = std::max<int64_t>(rows, 16 * (int64_t)m);         // at least 16 m sample rows
     tiles = (rows + tile_rows - 1) / tile_rows;
@@ -397,6 +403,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     uint32_t* tie_info = b.take<uint32_t>((size_t)cq_max * 4);
     unsigned long long* cand = b.take<unsigned long long>((size_t)cq_max * HDB_CAND_CAP);
     float* sbuf = b.take<float>((size_t)cq_max * (exact && !small ? ld_n : ld_s));
+    ix->dbg_buf = sbuf;
 
     LAUNCH_TRY(hdb_launch_qprep(dev_Q, nq, ix->d, f64, qinv, qsq, qnan, st));
     if (is_ham) {
@@ -427,10 +434,15 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
             s.ntiles = s_tiles; s.tile_stride = s_stride; s.scores = sbuf; s.ld = ld_s;
             rc = run_scan(ix, s, 0, cq, qb, mfma, st); if (rc) return rc;
             // 2) m-th largest sample score per query
-            HIP_TRY(hipMemsetAsync(hist, 0, (size_t)cq * 4 * HDB_RADIX_BINS * 4, st));
-            for (int p = 0; p < 4; ++p) LAUNCH_TRY(hdb_launch_hist(sbuf, s_rows, ld_s, cq, hist, p, m, st));
-            LAUNCH_TRY(hdb_launch_thr(hist, cq, 4, m, (uint32_t)s_rows, thr, cnt, st));
+            if (m <= 16) {
+                LAUNCH_TRY(hdb_launch_sample_thr(sbuf, s_rows, ld_s, cq, m, thr, cnt, st));
+            } else {
+                HIP_TRY(hipMemsetAsync(hist, 0, (size_t)cq * 4 * HDB_RADIX_BINS * 4, st));
+                for (int p = 0; p < 4; ++p) LAUNCH_TRY(hdb_launch_hist(sbuf, s_rows, ld_s, cq, hist, p, m, st));
+                LAUNCH_TRY(hdb_launch_thr(hist, cq, 4, m, (uint32_t)s_rows, thr, cnt, st));
+            }
             // 3) the pass over all of V
+            if (ix->debug_flags & 8) a.scores = sbuf;      // diagnostic stamps land in the (now idle) sample buffer
             prof_begin(ix, st);
             rc = run_scan(ix, a, 1, cq, qb, mfma, st); if (rc) return rc;
             prof_end(ix, st);

@@ -38,6 +38,8 @@ struct ScanArgs {
     uint32_t* cnt;          // [nq]
     unsigned long long* cand;  // [nq][cap]
     uint32_t cap;
+    int32_t nq;             // total number of queries behind Q
+    int32_t dbg;            // timing-only ablation bits (results are wrong when set): 1 no LDS-DMA, 2 no MFMA, 4 no filter
 };
 
 // ---- orderable float keys -----------------------------------------------------------------

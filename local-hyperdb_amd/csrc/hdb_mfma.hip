@@ -41,6 +41,16 @@ template <int N> __device__ __forceinline__ void hdb_wait_vmcnt() {
     else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
     else static_assert(N < 0, "add this vmcnt immediate");
 }
+__device__ __forceinline__ unsigned long long hdb_stamp() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+__device__ __forceinline__ unsigned long long hdb_stamp_real() {
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
 __device__ __forceinline__ void hdb_lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -95,34 +105,56 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
     }
     if (tid < 4) ctl[tid] = 0;
 
+    // ---- roles ----------------------------------------------------------------------------------------
+    // Waves 0-3 ("A") and 4-7 ("B") are the two waves of each SIMD.  An LDS-DMA instruction costs its wave
+    // ~90 issue cycles (48 of them per tile), so the staging of tile i+2 is split: B issues its half at the
+    // START of interval i and runs its threshold epilogue one tile late, A (raised priority) owns the
+    // matrix pipe first and issues its half at the END, while B multiplies.  Without this split both waves
+    // of a SIMD reach DMA issue, MFMA, epilogue and barrier together and the matrix pipe idles ~40 %.
+    const bool grpB = w >= 4;
+    constexpr int NLOADA = NG;
+    constexpr int NLOADB = NG + (AUX0 ? 1 : 0) + (HAS_BIAS ? 1 : 0);     // B also stages the per-row aux values
+
     // ---- staging geometry (per lane, fixed for the whole kernel) -----------------------------------
-    int g_row[NG], g_col[NG];
+    int g_off[NG];
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
         const int slot = (w + 8 * j) * 64 + lane;
         const int r = slot / CPR, cpos = slot - r * CPR;
-        g_row[j] = r;
-        g_col[j] = (cpos ^ (r & 15)) * 16;          // source chunk for this LDS slot (XOR swizzle)
+        g_off[j] = r * (D * 2) + (cpos ^ (r & 15)) * 16;   // source byte for this LDS slot (XOR swizzle of the chunk)
     }
     const char* Vb = reinterpret_cast<const char*>(a.V);
     const int64_t my_tiles = (a.ntiles > blockIdx.x) ? (a.ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
 
-    auto issue = [&](int64_t i, int st) {
+    // one LDS-DMA piece (1 KiB) of tile i into stage st
+    auto issue_piece = [&](int64_t i, int st, int j) {
         const int64_t t = blockIdx.x + i * gridDim.x;
         const int64_t row0 = t * a.tile_stride * R;
         const int64_t last = a.n - 1 - row0;          // >= 0
         char* sdst = smem + st * STAGE;
-#pragma unroll
-        for (int j = 0; j < NG; ++j) {
-            const int64_t rr = g_row[j] <= last ? g_row[j] : last;
-            const char* gp = Vb + (row0 + rr) * (int64_t)(D * 2) + g_col[j];
-            __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(gp), HDB_LDS_PTR(sdst + (w + 8 * j) * 1024), 16, 0, 0);
+        const char* tile_base = Vb + row0 * (int64_t)(D * 2);          // wave-uniform
+        unsigned int off = (unsigned int)g_off[j];
+        if (last < R - 1) {                                             // ragged last tile: clamp rows to the last one
+            const int r = g_off[j] / (D * 2);
+            const int rr = r <= (int)last ? r : (int)last;
+            off = (unsigned int)(g_off[j] + (rr - r) * (D * 2));
         }
-        if (AUX0 || HAS_BIAS) {
+        __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(tile_base + off), HDB_LDS_PTR(sdst + (w + 8 * j) * 1024), 16, 0, 0);
+    };
+    auto issue_aux = [&](int64_t i, int st) {
+        if ((AUX0 || HAS_BIAS) && grpB) {
+            const int64_t t = blockIdx.x + i * gridDim.x;
+            const int64_t row0 = t * a.tile_stride * R;
+            const int64_t last = a.n - 1 - row0;
             const int64_t rr = lane <= last ? lane : last;
             if (AUX0) __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(aux0g + row0 + rr), HDB_LDS_PTR(auxbuf + (st * 2 + 0) * 64), 4, 0, 0);
             if (HAS_BIAS) __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(a.bias + row0 + rr), HDB_LDS_PTR(auxbuf + (st * 2 + 1) * 64), 4, 0, 0);
         }
+    };
+    auto issue = [&](int64_t i, int st) {
+#pragma unroll
+        for (int j = 0; j < NG; ++j) issue_piece(i, st, j);
+        issue_aux(i, st);
     };
 
     auto flush = [&]() {
@@ -142,76 +174,194 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
     if (my_tiles > 0) issue(0, 0);
     if (my_tiles > 1) issue(1, 1);
 
+    const unsigned int smem_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(smem);
     const unsigned int ctl_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(ctl);
     const unsigned int cb_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(cb);
     const unsigned int cbq_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(cbq);
-    // per-lane LDS read base: row r31 of a 32-row tile, chunk selected per k-step
-    const int rd_base = r31 * CPR * 16;
-    const int rx = r31 & 15;
+    // per-lane LDS read address: row r31 of a 32-row tile; chunk (2s+h)^rx of k-step s is at
+    // byte (32s ^ hx) of the row image, hx = (h ^ rx) << 4  (2s and h occupy disjoint bits)
+    const unsigned int rd_base = (unsigned int)(r31 * CPR * 16);
+    const unsigned int hx = (unsigned int)((h ^ (r31 & 15)) << 4);
 
-    int st_cur = 0;
-    for (int64_t i = 0; i < my_tiles; ++i) {
-        if (i + 1 < my_tiles) hdb_wait_vmcnt<NLOAD>(); else hdb_wait_vmcnt<0>();
-        if (MODE == 1 && tid == 0) ctl[1 + (i & 1)] = (ctl[0] >= HDB_MFMA_CB / 2) ? 1u : 0u;
-        hdb_lds_barrier();                                   // tile i is in LDS; everyone is done with tile i-1
-        if (i + 2 < my_tiles) issue(i + 2, st_cur == 0 ? 2 : st_cur - 1);   // into the buffer tile i-1 used
-        if (MODE == 1 && ctl[1 + (i & 1)]) flush();
+    // threshold in the domain the epilogue compares in (see below); +inf for padding lanes
+    float thr_cmp = INFINITY;
+    if (MODE == 1 && q_ok) {
+        if (METRIC == 1 && !HAS_BIAS) { const float tc = thr_l / qinv_l; thr_cmp = tc - fabsf(tc) * 1e-6f; }
+        else thr_cmp = thr_l;
+    }
 
-        if (wave_active) {
-            const int64_t t = blockIdx.x + i * gridDim.x;
-            const int64_t row0 = t * a.tile_stride * R;
-            const char* sb = smem + st_cur * STAGE;
-            f32x16 acc[RT];
+    // Filter, second half: group maxima (v_max3) let the common no-hit case finish in ~25 VALU
+    // instructions; survivors go to the workgroup's LDS list.  `tv` holds comparable values (below).
+    auto filter = [&](const f32x16 (&tv)[RT], int64_t row0) {
+        float gm[RT][4];
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[rt][e] = 0.f;
-            // A fragments are fetched one k-step ahead (two register sets) so that the LDS latency of
-            // step s+1 hides under the MFMAs of step s.
-            half8 abuf[2][RT];
-            auto fetch = [&](int s, half8 (&dst)[RT]) {
-                const int cx = ((2 * s + h) ^ rx) << 4;
+            for (int g = 0; g < 4; ++g)
+                gm[rt][g] = fmaxf(fmaxf(tv[rt][4 * g], tv[rt][4 * g + 1]), fmaxf(tv[rt][4 * g + 2], tv[rt][4 * g + 3]));
+        float m = gm[0][0];
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    dst[rt] = *reinterpret_cast<const half8*>(sb + rt * 32 * CPR * 16 + rd_base + cx);
-            };
-            fetch(0, abuf[0]);
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                if (s + 1 < KS) fetch(s + 1, abuf[(s + 1) & 1]);
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(abuf[s & 1][rt], Bq[s], acc[rt], 0, 0, 0);
-                // pin the interleave: the reads of step s+1 go out BEFORE the MFMAs of step s
-                __builtin_amdgcn_sched_group_barrier(0x100, RT, 0);   // DS reads
-                __builtin_amdgcn_sched_group_barrier(0x008, RT, 0);   // MFMAs
-            }
-            // ---- epilogue: lane holds query q and rows rt*32 + 8g + 4h + j ----------------------------
-            const float* ax0 = auxbuf + (st_cur * 2 + 0) * 64;
-            const float* ax1 = auxbuf + (st_cur * 2 + 1) * 64;
+            for (int g = 0; g < 4; ++g) m = fmaxf(m, gm[rt][g]);
+        if (m >= thr_cmp) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int rl0 = rt * 32 + 8 * g + 4 * h;
-                    float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (AUX0) av = *reinterpret_cast<const float4*>(ax0 + rl0);
-                    if (HAS_BIAS) bv = *reinterpret_cast<const float4*>(ax1 + rl0);
-                    const float aj[4] = {av.x, av.y, av.z, av.w};
-                    const float bj[4] = {bv.x, bv.y, bv.z, bv.w};
-                    float sj[4];
+                    if (gm[rt][g] >= thr_cmp) {
+                        const int64_t rowg = row0 + rt * 32 + 8 * g + 4 * h;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float dot = acc[rt][4 * g + j];
-                        float s;
-                        if (METRIC == 0) s = dot;
-                        else if (METRIC == 1) s = dot * aj[j] * qinv_l;
-                        else { const float d2 = fmaxf(aj[j] + qsq_l - 2.f * dot, 0.f); s = 1.f / (1.f + sqrtf(d2)); }
-                        if (HAS_BIAS) s += bj[j];
-                        sj[j] = hdb_canon(s);
+                        for (int j = 0; j < 4; ++j) {
+                            const float x = tv[rt][4 * g + j];
+                            if (x >= thr_cmp && rowg + j < a.n) {
+                                const float sc = hdb_canon((METRIC == 1 && !HAS_BIAS) ? x * qinv_l : x);
+                                // LDS ops in inline asm: hipcc would otherwise drain every in-flight LDS-DMA
+                                // (s_waitcnt vmcnt(0)) before touching LDS it cannot prove disjoint from the ring.
+                                unsigned int pos;
+                                asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                                             : "=&v"(pos) : "v"(ctl_addr), "v"(1u) : "memory");
+                                if (pos < HDB_MFMA_CB) {
+                                    const unsigned long long ent = hdb_pack(sc, (uint32_t)(rowg + j));
+                                    asm volatile("ds_write_b64 %0, %1\n\tds_write_b16 %2, %3"
+                                                 :: "v"(cb_addr + pos * 8u), "v"(ent), "v"(cbq_addr + pos * 2u), "v"((unsigned int)ql) : "memory");
+                                } else {
+                                    atomicAdd(&a.cnt[ql], a.cap + 1u);   // LDS list overflowed: force the exact-path fallback
+                                }
+                            }
+                        }
                     }
-                    const int64_t rowg = row0 + rl0;
-                    if (MODE == 0) {
+                }
+            }
+        }
+    };
+
+    f32x16 acc[RT];
+    int64_t row0_prev = 0;
+    int st_cur = 0;
+    // diagnostic stamps (dbg & 8, timing study only): block 0, lane 0 of waves 0 and 4, first 64 tiles,
+    // 8 stamps per tile, written to the (otherwise unused in filter mode) scores pointer
+    const bool stamping = MODE == 1 && (a.dbg & 8) && blockIdx.x == 0 && lane == 0 && (w == 0 || w == 4);
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(a.scores) + (w == 4 ? 64 * 8 : 0);
+#define HDB_STAMP(k) do { if (stamping && i < 64) stamps[i * 8 + (k)] = hdb_stamp(); } while (0)
+    if (stamping) { stamps[2 * 64 * 8 + (w == 4 ? 2 : 0)] = hdb_stamp(); stamps[2 * 64 * 8 + (w == 4 ? 3 : 1)] = hdb_stamp_real(); }
+    for (int64_t i = 0; i < my_tiles; ++i) {
+        HDB_STAMP(0);
+        if (i + 1 >= my_tiles) hdb_wait_vmcnt<0>();
+        else if (grpB) hdb_wait_vmcnt<NLOADB>();
+        else hdb_wait_vmcnt<NLOADA>();
+        if (MODE == 1 && tid == 0) ctl[1 + (i & 1)] = (ctl[0] >= HDB_MFMA_CB / 2) ? 1u : 0u;
+        HDB_STAMP(1);
+        hdb_lds_barrier();                                   // tile i is in LDS; everyone is done with tile i-1
+        HDB_STAMP(2);
+        const bool more = i + 2 < my_tiles && !(a.dbg & 1);
+        const int st_next2 = st_cur == 0 ? 2 : st_cur - 1;      // buffer of tile i+2 == the one tile i-1 used
+        if (more) issue_aux(i + 2, st_next2);
+        if (more && !wave_active) {
+#pragma unroll
+            for (int j = 0; j < NG; ++j) issue_piece(i + 2, st_next2, j);
+        }
+        if (MODE == 1 && ctl[1 + (i & 1)]) flush();
+        HDB_STAMP(3);
+
+        if (wave_active) {
+            const int64_t t = blockIdx.x + i * gridDim.x;
+            const int64_t row0 = t * a.tile_stride * R;
+            if (MODE == 1 && grpB && i > 0 && !(a.dbg & 4)) filter(acc, row0_prev);        // deferred epilogue of tile i-1
+            HDB_STAMP(4);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[rt][e] = 0.f;
+
+            // A fragments: LDS reads issued one k-step ahead of the MFMAs that consume them.  The reads
+            // and their counted waits are inline asm so that hipcc cannot sink a read next to its use
+            // (it otherwise emits read, lgkmcnt(0), MFMA per step and exposes the LDS latency 24 times).
+            // lgkmcnt(RT) = "all but the RT newest LDS ops are back" = the previous step's fragments;
+            // stray scalar loads can only make that wait longer, never shorter.
+            const unsigned int sb_addr = smem_addr + (unsigned int)(st_cur * STAGE) + rd_base;
+            half8 abuf[3][RT];
+            auto fetch = [&](int s, half8 (&dst)[RT]) {
+                const unsigned int ad = sb_addr + ((unsigned int)(32 * s) ^ hx);
+                asm volatile("ds_read_b128 %0, %1" : "=v"(dst[0]) : "v"(ad));
+                if constexpr (RT > 1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[1]) : "v"(ad), "i"(32 * CPR * 16));
+            };
+            auto wait_frag = [&](int pending_steps, half8 (&f)[RT]) {     // fragments of the oldest step are back
+                if constexpr (RT > 1) {
+                    if (pending_steps == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f[0]), "+v"(f[1]));
+                    else if (pending_steps == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(f[0]), "+v"(f[1]));
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]));
+                } else {
+                    if (pending_steps == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(f[0]));
+                    else if (pending_steps == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(f[0]));
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]));
+                }
+            };
+            if (!grpB && !(a.dbg & 16)) __builtin_amdgcn_s_setprio(2);
+            if (!(a.dbg & 2)) {
+            fetch(0, abuf[0]);
+            if (KS > 1) fetch(1, abuf[1]);
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if (s + 2 < KS) fetch(s + 2, abuf[(s + 2) % 3]);
+                wait_frag(s + 2 < KS ? 2 : (s + 1 < KS ? 1 : 0), abuf[s % 3]);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+                    acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(abuf[s % 3][rt], Bq[s], acc[rt], 0, 0, 0);
+                // LDS-DMA pieces of tile i+2 ride between the MFMAs: one every KS/NG k-steps
+                constexpr int EVERY = KS / NG;
+                if (s % EVERY == EVERY / 2 && s / EVERY < NG) { if (more) issue_piece(i + 2, st_next2, s / EVERY); }
+            }
+            } else if (more) {
+#pragma unroll
+                for (int j = 0; j < NG; ++j) issue_piece(i + 2, st_next2, j);
+            }
+            if (!grpB) __builtin_amdgcn_s_setprio(0);
+            HDB_STAMP(5);
+
+            // ---- epilogue, first half: lane holds query q and rows rt*32 + 8g + 4h + j (register 4g+j).
+            // Turn the dot products into the values that are stored (MODE 0) or compared (MODE 1), in place.
+            // Filter mode compares the score itself, except cosine without bias: dot/||v|| vs thr/qinv.
+            const float* ax0 = auxbuf + (st_cur * 2 + 0) * 64;
+            const float* ax1 = auxbuf + (st_cur * 2 + 1) * 64;
+            if (METRIC != 0 || HAS_BIAS) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int rl0 = rt * 32 + 8 * g + 4 * h;
+                        float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (AUX0) av = *reinterpret_cast<const float4*>(ax0 + rl0);
+                        if (HAS_BIAS) bv = *reinterpret_cast<const float4*>(ax1 + rl0);
+                        const float aj[4] = {av.x, av.y, av.z, av.w};
+                        const float bj[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float dot = acc[rt][4 * g + j];
+                            float x;
+                            if (METRIC == 0) x = dot + bj[j];
+                            else if (METRIC == 1) {
+                                if (MODE == 1 && !HAS_BIAS) x = dot * aj[j];
+                                else x = HAS_BIAS ? fmaf(dot * aj[j], qinv_l, bj[j]) : dot * aj[j] * qinv_l;
+                            } else {
+                                const float d2 = fmaxf(aj[j] + qsq_l - 2.f * dot, 0.f);
+                                x = 1.f / (1.f + sqrtf(d2)) + (HAS_BIAS ? bj[j] : 0.f);
+                            }
+                            acc[rt][4 * g + j] = x;
+                        }
+                    }
+                }
+            }
+            if (MODE == 0) {
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int rl0 = rt * 32 + 8 * g + 4 * h;
+                        const int64_t rowg = row0 + rl0;
+                        float sj[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) sj[j] = hdb_canon(acc[rt][4 * g + j]);
                         if (q_ok) {
                             float* dst = a.scores + (int64_t)ql * a.ld + (t * R + rl0);
                             if (rowg + 3 < a.n) *reinterpret_cast<float4*>(dst) = make_float4(sj[0], sj[1], sj[2], sj[3]);
@@ -220,31 +370,22 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
                                 for (int j = 0; j < 4; ++j) if (rowg + j < a.n) dst[j] = sj[j];
                             }
                         }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            if (q_ok && rowg + j < a.n && sj[j] >= thr_l) {
-                                // LDS ops in inline asm: hipcc would otherwise drain every in-flight LDS-DMA
-                                // (s_waitcnt vmcnt(0)) before touching LDS it cannot prove disjoint from the ring.
-                                unsigned int pos;
-                                asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
-                                             : "=&v"(pos) : "v"(ctl_addr), "v"(1u) : "memory");
-                                if (pos < HDB_MFMA_CB) {
-                                    const unsigned long long ent = hdb_pack(sj[j], (uint32_t)(rowg + j));
-                                    asm volatile("ds_write_b64 %0, %1\n\tds_write_b16 %2, %3"
-                                                 :: "v"(cb_addr + pos * 8u), "v"(ent), "v"(cbq_addr + pos * 2u), "v"((unsigned int)ql) : "memory");
-                                } else {
-                                    atomicAdd(&a.cnt[ql], a.cap + 1u);     // LDS list overflowed: force the exact-path fallback
-                                }
-                            }
-                        }
                     }
                 }
+            } else {
+                if (!grpB) { if (!(a.dbg & 4)) filter(acc, row0); }
+                else row0_prev = row0;
             }
+            HDB_STAMP(6);
         }
         st_cur = st_cur == 2 ? 0 : st_cur + 1;
     }
-    if (MODE == 1) flush();
+    if (stamping) { stamps[2 * 64 * 8 + (w == 4 ? 6 : 4)] = hdb_stamp(); stamps[2 * 64 * 8 + (w == 4 ? 7 : 5)] = hdb_stamp_real(); }
+#undef HDB_STAMP
+    if (MODE == 1) {
+        if (wave_active && grpB && my_tiles > 0) filter(acc, row0_prev);
+        flush();
+    }
 }
 
 // fp32 -> fp16 queries (round to nearest even, like numpy's astype(float16))

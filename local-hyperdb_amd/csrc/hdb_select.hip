@@ -119,6 +119,61 @@ __global__ __launch_bounds__(64) void hdb_thr_kernel(const uint32_t* hist, int n
     }
 }
 
+// Sample threshold in ONE launch (m <= 16): one workgroup per query.  Every thread keeps only the maximum of
+// its strided share of the sample; the m-th largest of those 1024 maxima is a lower bound of the m-th largest
+// sample score (order statistics of a subset), and equals it unless two of the top m fell to one thread
+// (a few % of cases, then it is the (m+1)-th or so).  A lower bound is all the filter needs: the threshold only
+// has to keep >= k rows and not too many.  No histograms, no LDS atomics: wave-level max extraction only.
+// thr[q] = that bound, cnt[q] = 0.  Replaces memset + 4 x hdb_hist_kernel + hdb_thr_kernel per query.
+__device__ __forceinline__ uint32_t hdb_wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
+    return v;
+}
+__global__ __launch_bounds__(1024) void hdb_sample_thr_kernel(const float* scores, int64_t n, int64_t ld, uint32_t m,
+                                                              float* thr, uint32_t* cnt) {
+    __shared__ uint32_t top[16 * 16];
+    const int q = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* sq = scores + (int64_t)q * ld;
+    uint32_t best = 0u;                                  // key 0 is below every real score, even -inf
+    const int64_t n4 = n / 4;
+    const float4* sq4 = reinterpret_cast<const float4*>(sq);   // ld and base are multiples of 4 floats / 16 bytes
+    for (int64_t i = threadIdx.x; i < n4; i += 1024) {
+        const float4 v = sq4[i];
+        best = max(max(best, hdb_f2key(v.x)), max(max(hdb_f2key(v.y), hdb_f2key(v.z)), hdb_f2key(v.w)));
+    }
+    for (int64_t i = n4 * 4 + threadIdx.x; i < n; i += 1024) best = max(best, hdb_f2key(sq[i]));
+    // wave: extract its m largest maxima
+    uint32_t v = best;
+    for (uint32_t r = 0; r < m; ++r) {
+        const uint32_t wm = hdb_wave_max_u32(v);
+        const unsigned long long who = __ballot(v == wm);
+        if (lane == (int)__ffsll((long long)who) - 1) v = 0u;
+        if (lane == 0) top[wave * 16 + r] = wm;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // 16 waves x m values: lane holds up to 4 of them
+        uint32_t c[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int e = lane + 64 * j; c[j] = (uint32_t)(e & 15) < m ? top[e] : 0u; }
+        uint32_t kth = 0u;
+        for (uint32_t r = 0; r < m; ++r) {
+            const uint32_t lm = max(max(c[0], c[1]), max(c[2], c[3]));
+            const uint32_t wm = hdb_wave_max_u32(lm);
+            const unsigned long long who = __ballot(lm == wm);
+            if (lane == (int)__ffsll((long long)who) - 1) {
+                if (c[0] == wm) c[0] = 0u; else if (c[1] == wm) c[1] = 0u; else if (c[2] == wm) c[2] = 0u; else c[3] = 0u;
+            }
+            kth = wm;
+        }
+        if (lane == 0) {
+            thr[q] = (n < (int64_t)m || kth == 0u) ? -INFINITY : hdb_key2f(kth);
+            cnt[q] = 0;
+        }
+    }
+}
+
 __global__ void hdb_fill_thr_kernel(float* thr, uint32_t* cnt, int nq, float v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nq) { thr[i] = v; cnt[i] = 0; }
@@ -216,17 +271,82 @@ __device__ __forceinline__ void hdb_bitonic_desc(unsigned long long* buf, int P)
     }
 }
 
+// Pre-selection for finalize/merge: keeps (in buf[0..ns)) a superset of the kk largest of buf[0..nc) that is
+// usually only a little larger than kk, so that the O(log^2) bitonic network runs on ~256 instead of ~4096
+// entries.  Monotone linear binning of the 32-bit score key into 2048 bins between the smallest and the
+// largest key present; everything in or above the bin holding the kk-th largest survives.  Exactness is
+// untouched: the survivors always contain the true top-kk, ties included.  Returns ns (>= min(kk, nc)).
+// hist: 2048 words of LDS; scratch: nc u64 of LDS (may alias nothing else).
+__device__ uint32_t hdb_preselect(unsigned long long* buf, uint32_t nc, uint32_t kk, uint32_t* hist,
+                                  unsigned long long* scratch, uint32_t* ctl /* 8 words */) {
+    const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nth >> 6;
+    constexpr uint32_t NB = 2048;
+    // min / max key
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+    for (uint32_t i = tid; i < nc; i += nth) { const uint32_t k = (uint32_t)(buf[i] >> 32); kmin = min(kmin, k); kmax = max(kmax, k); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o, 64)); kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64)); }
+    if (tid < 8) ctl[tid] = tid == 0 ? 0xFFFFFFFFu : 0u;
+    for (uint32_t i = tid; i < NB; i += nth) hist[i] = 0;
+    __syncthreads();
+    if (lane == 0) { atomicMin(&ctl[0], kmin); atomicMax(&ctl[1], kmax); }
+    __syncthreads();
+    kmin = ctl[0]; kmax = ctl[1];
+    const unsigned long long span = (unsigned long long)(kmax - kmin) + 1ull;
+    auto bin_of = [&](uint32_t k) { return (uint32_t)(((unsigned long long)(k - kmin) * NB) / span); };
+    for (uint32_t i = tid; i < nc; i += nth) atomicAdd(&hist[bin_of((uint32_t)(buf[i] >> 32))], 1u);
+    __syncthreads();
+    // suffix scan from the top bin: thread t owns bins NB-1-2t, NB-2-2t (1024 threads) -- generic stride
+    const uint32_t per = (NB + nth - 1) / nth;
+    uint32_t loc[4]; uint32_t tot = 0;
+    for (uint32_t j = 0; j < per; ++j) { const uint32_t b = tid * per + j; loc[j] = b < NB ? hist[NB - 1 - b] : 0; tot += loc[j]; }
+    uint32_t incl = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    uint32_t* wsum = hist;      // reuse after everyone has read its bins
+    __syncthreads();
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t before = incl - tot;
+    for (int w2 = 0; w2 < wave; ++w2) before += wsum[w2];
+    for (uint32_t j = 0; j < per; ++j) {
+        if (before < kk && kk <= before + loc[j]) ctl[2] = NB - 1 - (tid * per + j);     // the bin holding the kk-th largest
+        before += loc[j];
+    }
+    __syncthreads();
+    const uint32_t bsel = ctl[2];
+    // compact survivors
+    for (uint32_t i = tid; i < nc; i += nth) {
+        const unsigned long long e = buf[i];
+        if (bin_of((uint32_t)(e >> 32)) >= bsel) scratch[atomicAdd(&ctl[3], 1u)] = e;
+    }
+    __syncthreads();
+    const uint32_t ns = ctl[3];
+    for (uint32_t i = tid; i < ns; i += nth) buf[i] = scratch[i];
+    __syncthreads();
+    (void)nwaves;
+    return ns;
+}
+
+// LDS carve for finalize/merge: buf (cap u64) | scratch (cap u64) | hist (2048 u32) | ctl (8 u32)
 __global__ __launch_bounds__(1024) void hdb_finalize_kernel(const unsigned long long* cand, const uint32_t* cnt,
                                                             uint32_t cap, uint32_t k, uint32_t kk /* min(k, n) */,
                                                             int64_t row_base, int64_t* idx_out, float* score_out,
                                                             int32_t* status, const int* qnan) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long buf[];
+    unsigned long long* scratch = buf + cap;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(scratch + cap);
+    uint32_t* ctl = hist + 2048;
     const int q = blockIdx.x;
     const uint32_t total = cnt[q];
     const uint32_t nc = total < cap ? total : cap;
+    for (uint32_t i = threadIdx.x; i < nc; i += blockDim.x) buf[i] = cand[(int64_t)q * cap + i];
+    __syncthreads();
+    uint32_t ns = nc;
+    if (nc > 512 && kk < nc / 2) ns = hdb_preselect(buf, nc, kk, hist, scratch, ctl);
     int P = 64;
-    while ((uint32_t)P < nc) P <<= 1;
-    for (int i = threadIdx.x; i < P; i += blockDim.x) buf[i] = (uint32_t)i < nc ? cand[(int64_t)q * cap + i] : 0ull;
+    while ((uint32_t)P < ns) P <<= 1;
+    for (int i = ns + threadIdx.x; i < P; i += blockDim.x) buf[i] = 0ull;
     __syncthreads();
     hdb_bitonic_desc(buf, P);
     for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
@@ -243,7 +363,7 @@ __global__ __launch_bounds__(1024) void hdb_finalize_kernel(const unsigned long 
         int32_t st = 0;
         if (total > cap) st |= HDB_Q_OVERFLOW;
         if (nc < kk) st |= HDB_Q_UNDERFLOW;
-        if (qnan && qnan[q]) st |= 4;
+        if (qnan && qnan[q]) st |= HDB_Q_NAN;
         status[q] = st;
     }
 }
@@ -308,6 +428,10 @@ extern "C" int hdb_launch_thr(const uint32_t* hist, int nq, int npass, uint32_t 
     hipLaunchKernelGGL(hdb_thr_kernel, dim3(nq), dim3(64), 0, (hipStream_t)stream, hist, npass, m, sample_n, thr, cnt);
     return (int)hipGetLastError();
 }
+extern "C" int hdb_launch_sample_thr(const float* scores, int64_t n, int64_t ld, int nq, uint32_t m, float* thr, uint32_t* cnt, void* stream) {
+    hipLaunchKernelGGL(hdb_sample_thr_kernel, dim3(nq), dim3(1024), 0, (hipStream_t)stream, scores, n, ld, m, thr, cnt);
+    return (int)hipGetLastError();
+}
 extern "C" int hdb_launch_fill_thr(float* thr, uint32_t* cnt, int nq, float v, void* stream) {
     hipLaunchKernelGGL(hdb_fill_thr_kernel, dim3((nq + 255) / 256), dim3(256), 0, (hipStream_t)stream, thr, cnt, nq, v);
     return (int)hipGetLastError();
@@ -322,7 +446,14 @@ extern "C" int hdb_launch_collect(const float* scores, int64_t n, int64_t ld, in
 extern "C" int hdb_launch_finalize(const unsigned long long* cand, const uint32_t* cnt, uint32_t cap, int nq, uint32_t k,
                                    uint32_t kk, int64_t row_base, int64_t* idx_out, float* score_out, int32_t* status,
                                    const int* qnan, void* stream) {
-    hipLaunchKernelGGL(hdb_finalize_kernel, dim3(nq), dim3(1024), (size_t)HDB_CAND_CAP * 8, (hipStream_t)stream, cand, cnt, cap, k, kk,
+    const size_t lds = (size_t)cap * 16 + 2048 * 4 + 64;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hdb_finalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(hdb_finalize_kernel, dim3(nq), dim3(1024), lds, (hipStream_t)stream, cand, cnt, cap, k, kk,
                        row_base, idx_out, score_out, status, qnan);
     return (int)hipGetLastError();
 }
