@@ -1,2 +1,276 @@
-"""HyperDB facade for the GPU ranking path (placeholder: filled in by the facade milestone)."""
-__all__ = []
+"""``HyperDB`` facade over the MI355X ranking path (counterpart of reference hyperdb/hyperdb.py).
+
+Scope: ONLY what sits either side of the hot path -- the constructor that
+takes documents + precomputed vectors, ``query()`` with the reference's signature and return shapes,
+and the ~30 lines of ``_execute_query`` around the ranking call (hyperdb.py:1461-1469, :1541-1575).
+Everything else the reference class does (sentence-transformer embedding, Annoy, pickle/sqlite
+persistence, text filters) is out of scope and is NOT re-implemented here.
+
+Differences from the reference, all deliberate:
+  * the N x d matrix is registered once on the GPU (``GpuIndex``) -- no per-query NaN scan, copy or
+    re-normalisation (ranking_algorithm.py:150,:153,:37);
+  * exact search always: the Annoy branch (hyperdb.py:1484-1487, :1546-1552) is bypassed, because a full
+    HBM scan (~1.4 ms at N=10M) is faster than the reference's ANN candidate filtering and needs no
+    O(N) Python index rebuild on every add/remove (hyperdb.py:218-220);
+  * ranked rows map to documents by row id, O(k), instead of ``self.documents.index(document)``
+    (hyperdb.py:1568, O(N) dict comparisons per hit);
+  * ``filters``: ``skip_doc`` and ``metadata`` equality filters become a device row mask; the text filters
+    (``key``, ``sentence``) need the embedding model and raise NotImplementedError;
+  * strings can be queried only when an ``embedding_function`` is supplied (no model download).
+Kept from the reference: argument names and defaults, metric whitelist and messages, the top_k warning,
+``(document, score, source_index)`` / ``document`` return shapes, the LRU result cache, and the DOUBLE
+application of the recency decay when going through ``query()`` (hyperdb.py:1344 then
+ranking_algorithm.py:183).
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import numpy as np
+
+from . import ranking_algorithm as ranking
+from ._native import GpuIndex, METRIC_IDS
+
+__all__ = ["HyperDB"]
+
+_METRICS = ['dot_product', 'cosine_similarity', 'euclidean_metric', 'manhattan_distance', 'jaccard_similarity',
+            'pearson_correlation', 'hamming_distance']
+
+
+class HyperDB:
+    def __init__(self, documents=None, vectors=None, select_keys=None, embedding_function=None, fp_precision="float32",
+                 add_timestamp=False, metadata_keys=None, ann_metric="cosine", n_trees=10, cache_size=256, device=None):
+        if fp_precision not in ["float16", "float32", "float64"]:
+            raise ValueError("Unsupported floating-point precision.")                       # hyperdb.py:65-66
+        accepted = ["angular", "euclidean", "manhattan", "hamming", "dot", "cosine"]
+        if ann_metric not in accepted:
+            raise ValueError(f"Unsupported ANN metric. Accepted values are: {', '.join(accepted)}")  # :69-71
+        self.fp_precision = getattr(np, fp_precision)
+        self.embedding_function = embedding_function
+        self.select_keys = [select_keys] if isinstance(select_keys, str) else select_keys
+        self.metadata_keys = [metadata_keys] if isinstance(metadata_keys, str) else (metadata_keys or [])
+        self.add_timestamp = add_timestamp
+        self.ann_metric, self.n_trees = ann_metric, n_trees          # accepted for compatibility; no ANN is built
+        self.device = device
+        self.documents, self.source_indices = [], []
+        self.vectors = None
+        self._index = None
+        self._cache = OrderedDict()
+        self._cache_size = cache_size
+        self.cache_hits = self.cache_misses = 0
+        if documents is not None or vectors is not None:
+            self.add(documents, vectors)
+
+    # ---------------------------------------------------------------- matrix lifecycle (hyperdb.py:496-766)
+    def _embed(self, documents):
+        if self.embedding_function is None:
+            raise ValueError("vectors must be given: this build ships no embedding model "
+                             "(pass vectors=... or an embedding_function).")
+        return np.asarray(self.embedding_function(documents))
+
+    def add(self, documents, vectors=None, add_timestamp=None):
+        """Append documents with their vectors (hyperdb.py:548-566 without chunking/embedding)."""
+        if documents is None:
+            raise ValueError("documents are required")
+        if not isinstance(documents, list):
+            documents = [documents]
+        if vectors is None:
+            vectors = self._embed(documents)
+        vectors = np.asarray(vectors)
+        if vectors.ndim == 1:
+            vectors = vectors.reshape(1, -1)
+        if vectors.ndim != 2 or len(vectors) != len(documents):
+            raise ValueError("All vectors must have the same dimension, one per document.")   # hyperdb.py:139-164
+        vectors = vectors.astype(self.fp_precision, copy=False)
+        start = len(self.documents)
+        self.documents = list(self.documents) + list(documents)
+        self.source_indices = list(self.source_indices) + list(range(start, start + len(documents)))
+        self.vectors = vectors if self.vectors is None else np.concatenate([self.vectors, vectors], axis=0)
+        self._refresh()
+
+    def remove_document(self, index):
+        """Drop rows by index or list of indices (hyperdb.py:691-766, matrix part)."""
+        drop = np.atleast_1d(np.asarray(index, dtype=np.int64))
+        keep = np.ones(len(self.documents), dtype=bool)
+        keep[drop] = False
+        self.vectors = self.vectors[keep]
+        self.documents = [d for d, k in zip(self.documents, keep) if k]
+        self.source_indices = [s for s, k in zip(self.source_indices, keep) if k]
+        self._refresh()
+
+    def _refresh(self):
+        self.clear_cache()
+        if self.vectors is None or len(self.vectors) == 0:
+            if self._index is not None:
+                self._index.close()
+            self._index = None
+            return
+        if self._index is None or self._index.d != self.vectors.shape[1]:
+            if self._index is not None:
+                self._index.close()
+            self._index = GpuIndex(self.vectors, device=self.device)
+        else:
+            self._index.update(self.vectors)
+
+    def size(self):
+        return len(self.documents)
+
+    # ---------------------------------------------------------------- LRU cache (hyperdb.py:1368-1427)
+    def clear_cache(self):
+        self._cache.clear()
+        self.cache_hits = self.cache_misses = 0
+
+    def get_cache_size_and_info(self):
+        return {'cache_info': {'hits': self.cache_hits, 'misses': self.cache_misses, 'maxsize': self._cache_size,
+                               'currsize': len(self._cache)}}
+
+    @staticmethod
+    def _hashable_key(query_input, top_k, return_similarities, filters, recency_bias, timestamp_key, metric, ann_percent):
+        if isinstance(query_input, np.ndarray):
+            query_input = tuple(query_input.ravel().tolist()) + (query_input.shape,)
+        elif isinstance(query_input, list):
+            query_input = tuple(np.asarray(query_input).ravel().tolist())
+        if filters is None:
+            hf = None
+        else:
+            hf = tuple((name, tuple(sorted(p.items())) if isinstance(p, dict) else tuple(p) if isinstance(p, list) else p)
+                       for name, p in filters)
+        return (query_input, top_k, return_similarities, hf, recency_bias, timestamp_key, metric, ann_percent)
+
+    # ---------------------------------------------------------------- helpers around the ranking call
+    @staticmethod
+    def get_nested_value(dictionary, keys):
+        value = dictionary
+        for key in keys:
+            if isinstance(value, dict):
+                value = value.get(key)
+            else:
+                return None
+        return value
+
+    def _handle_timestamps(self, recency_bias, timestamp_key, documents):
+        """First application of the decay: rb * exp(ts - max ts) (hyperdb.py:1310-1346)."""
+        if recency_bias == 0:
+            return None
+        if timestamp_key is None:
+            timestamp_key = "timestamp"
+        if timestamp_key not in self.metadata_keys:
+            raise ValueError(f"The timestamp_key '{timestamp_key}' must be present in metadata_keys when recency_bias is not 0.")
+        nested = timestamp_key.split('.') if '.' in timestamp_key else [timestamp_key]
+        ts = [self.get_nested_value(doc, nested) for doc in documents]
+        if None in ts:
+            raise ValueError("All timestamps must be populated when recency_bias is not 0 or timestamp_key is provided.")
+        ts = np.array(ts, dtype=float)
+        return recency_bias * np.exp(-np.max(ts) + ts)
+
+    def _query_vectors(self, query_input):
+        """hyperdb.py:1178-1216: strings are embedded, arrays validated; returns (nq, d) float array."""
+        if isinstance(query_input, str):
+            q = np.asarray(self._embed([query_input]))
+        elif isinstance(query_input, (list, np.ndarray, tuple)):
+            q = np.array(query_input)
+            if not (np.issubdtype(q.dtype, np.number)):
+                raise ValueError("Numeric array-like query_input expected.")
+        else:
+            raise ValueError("query_input must be either a string or a numeric array-like object.")
+        if q.ndim > 2:
+            raise ValueError("query_input must be a 1D or 2D array.")
+        if q.ndim == 1:
+            q = q.reshape(1, -1)
+        if q.size == 0:
+            raise ValueError("The generated query vector is empty.")
+        if q.shape[1] != self.vectors.shape[1]:
+            raise ValueError(f"The dimension of the query_vector ({q.shape[1]}) must match the dimension of the vectors "
+                             f"in the database ({self.vectors.shape[1]}).")
+        return q
+
+    def _row_mask(self, filters):
+        """skip_doc (hyperdb.py:1119-1134) and metadata equality filters -> boolean row mask, or None."""
+        if not filters:
+            return None
+        n = len(self.documents)
+        keep = np.ones(n, dtype=bool)
+        for name, params in filters:
+            if name == 'skip_doc':
+                if abs(params) >= n:
+                    print(f"The absolute value of skip_doc ({abs(params)}) is equal or greater than the total number of documents ({n}).")
+                    raise Exception("The absolute value of skip_doc is equal or greater than the total number of documents")
+                if params > 0:
+                    keep[:params] = False
+                elif params < 0:
+                    keep[n + params:] = False
+            elif name == 'metadata':
+                for key, want in params.items():
+                    nested = key.split('.')
+                    keep &= np.array([self.get_nested_value(doc, nested) == want if isinstance(doc, dict) else False
+                                      for doc in self.documents])
+            else:
+                raise NotImplementedError(f"filter '{name}' needs the text/embedding pipeline, which is out of scope here")
+        return keep
+
+    # ---------------------------------------------------------------- query (hyperdb.py:1429-1586)
+    def _execute(self, Q, top_k, return_similarities, filters, recency_bias, timestamp_key, metric):
+        if self.vectors is None or len(self.vectors) == 0 or not self.documents:
+            raise Exception("The database is empty. Cannot proceed with the query.")
+        if metric not in _METRICS:
+            raise ValueError(f"Invalid metric '{metric}'. Supported: " + ", ".join(f"'{m}'" for m in _METRICS))
+        ranking._validate_metric(metric)
+        ix = self._index
+        if ix.has_nan or np.isnan(Q).any():
+            raise ValueError(ranking.NAN_MESSAGE)
+        mask = self._row_mask(filters)
+        n_avail = len(self.documents) if mask is None else int(mask.sum())
+        if n_avail == 0:
+            print("INFO: No document matches your query with the brute-force method and the current filters.")
+            return [[] for _ in range(len(Q))]
+        if top_k > n_avail:
+            print(f"Warning: top_k ({top_k}) is greater than the number of filtered documents ({n_avail}). Setting top_k to {n_avail}.")
+            top_k = n_avail
+        first = self._handle_timestamps(recency_bias, timestamp_key, self.documents)     # decay #1 (host, float64)
+        try:
+            ix.set_row_mask(mask)
+            if first is not None:
+                ix.set_recency(first, recency_bias)                                     # decay #2, ranking_algorithm.py:183
+            idx, sc = ix.topk(Q, int(top_k), METRIC_IDS[metric])
+        finally:
+            ix.set_row_mask(None)
+            ix.set_bias(None)
+        out = []
+        for qi in range(len(Q)):
+            rows = idx[qi]
+            if return_similarities:
+                out.append([(self.documents[r], float(sc[qi][j]), self.source_indices[r]) for j, r in enumerate(rows) if r >= 0])
+            else:
+                out.append([self.documents[r] for r in rows if r >= 0])
+        return out
+
+    def query(self, query_input, top_k=5, return_similarities=True, filters=None, recency_bias=0, timestamp_key=None,
+              metric='cosine_similarity', ann_percent=5):
+        """Same signature and return shape as reference HyperDB.query (hyperdb.py:1584): a list of
+        ``(document, score, source_index)`` tuples (or documents) for ONE query."""
+        key = self._hashable_key(query_input, top_k, return_similarities, filters, recency_bias, timestamp_key, metric, ann_percent)
+        if key in self._cache:
+            self.cache_hits += 1
+            self._cache.move_to_end(key)
+            return self._cache[key]
+        self.cache_misses += 1
+        try:
+            if self.vectors is None or len(self.vectors) == 0 or not self.documents:
+                raise Exception("The database is empty. Cannot proceed with the query.")
+            Q = self._query_vectors(query_input)
+            if len(Q) != 1:
+                raise ValueError("query() takes one query; use query_batch() for a (Q, d) batch.")
+            result = self._execute(Q, top_k, return_similarities, filters, recency_bias, timestamp_key, metric)[0]
+        except (ValueError, TypeError) as e:
+            print(f"An exception occurred due to invalid input: {e}")
+            raise
+        self._cache[key] = result
+        if len(self._cache) > self._cache_size:
+            self._cache.popitem(last=False)
+        return result
+
+    def query_batch(self, query_inputs, top_k=5, return_similarities=True, filters=None, recency_bias=0, timestamp_key=None,
+                    metric='cosine_similarity'):
+        """Additive: one list of results per row of a (Q, d) batch, computed in a single pass over the matrix."""
+        Q = self._query_vectors(query_inputs)
+        return self._execute(Q, top_k, return_similarities, filters, recency_bias, timestamp_key, metric)

@@ -1,0 +1,132 @@
+"""Row-sharded index over torch.distributed with the gloo backend, world_size 2, on CPU.
+
+What is under test is the HOST logic of hyperdb/sharded.py: shard bounds, the packed exchange record
+([idx int64 | score f32 | status i32]), ONE all-gather per batch, merge ordering, global row ids, and
+the collective exact re-run when any shard reports a failed threshold.  The compute engine is a
+CPU stand-in defined HERE, in tests/, on top of the oracle -- the product engine (HipEngine) needs a
+GPU and is covered by tests/test_gpu_parity.py::test_shard_merge_equals_global.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+METRICS = {0: "dot_product", 1: "cosine_similarity", 2: "euclidean_metric", 3: "hamming_distance"}
+
+
+class OracleEngine:
+    """CPU stand-in with the HipEngine interface (test infrastructure only)."""
+
+    def __init__(self, V_local, row_base, fail_query=None):
+        from oracle import ranking_oracle as orc
+        from hyperdb import _native
+        self.orc, self.nat = orc, _native
+        self.V, self.row_base, self.fail_query = V_local, row_base, fail_query
+        self.device = torch.device("cpu")
+        self.exact_calls = 0
+
+    def packed_bytes(self, nq, k):
+        return self.nat.packed_bytes(nq, k)        # the C function: layout comes from the library
+
+    def new_record(self, nbytes):
+        return torch.zeros(nbytes, dtype=torch.uint8)
+
+    def _views(self, record, nq, k):
+        h = record.numpy()
+        return (h[:nq * k * 8].view(np.int64).reshape(nq, k), h[nq * k * 8:nq * k * 12].view(np.float32).reshape(nq, k),
+                h[nq * k * 12:nq * k * 12 + nq * 4].view(np.int32))
+
+    def topk_packed(self, Q, k, metric_id, record, exact=False):
+        nq = Q.shape[0]
+        idx, sc, st = self._views(record, nq, k)
+        idx[:], sc[:], st[:] = -1, -np.inf, 0
+        if exact:
+            self.exact_calls += 1
+        for qi in range(nq):
+            ex = self.orc.exact_scores(self.V, Q[qi].numpy(), METRICS[metric_id]).astype(np.float32)
+            order = np.lexsort((np.arange(len(ex)), -ex))[:k]
+            idx[qi, :len(order)] = order + self.row_base
+            sc[qi, :len(order)] = ex[order]
+            if not exact and self.fail_query is not None and qi == self.fail_query:
+                st[qi] = 1                               # pretend the sampled threshold underflowed here
+                idx[qi], sc[qi] = -1, -np.inf
+
+    def merge_packed_into(self, gathered, parts, nq, k, out_record):
+        nb = self.packed_bytes(nq, k)
+        oi, osc, ost = self._views(out_record, nq, k)
+        ost[:] = 0
+        cand_i, cand_s = [], []
+        for p in range(parts):
+            i, s, st = self._views(gathered[p * nb:(p + 1) * nb], nq, k)
+            cand_i.append(i.copy()); cand_s.append(s.copy()); ost |= st
+        ci, cs = np.concatenate(cand_i, axis=1), np.concatenate(cand_s, axis=1)
+        for qi in range(nq):
+            ok = ci[qi] >= 0
+            ii, ss = ci[qi][ok], cs[qi][ok]
+            order = np.lexsort((ii, -ss))[:k]
+            oi[qi], osc[qi] = -1, -np.inf
+            oi[qi, :len(order)], osc[qi, :len(order)] = ii[order], ss[order]
+
+    def record_to_host(self, record, nq, k):
+        return self._views(record, nq, k)
+
+    def select_queries(self, Q, which):
+        return Q[torch.as_tensor(which)]
+
+
+def _worker(rank, world, port, n, d, k, metric_id, fail_rank, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "local-hyperdb_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hyperdb.sharded import ShardedIndex, shard_bounds
+        rng = np.random.default_rng(77)
+        V = rng.standard_normal((n, d)).astype(np.float32)
+        V[n // 2 + 3] = V[5]                              # a duplicate row across shards: tie -> lower global row first
+        Q = torch.from_numpy(rng.standard_normal((4, d)).astype(np.float32))
+        lo, hi = shard_bounds(n, world, granule=16)[rank]
+        eng = OracleEngine(V[lo:hi], lo, fail_query=2 if rank == fail_rank else None)
+        sh = ShardedIndex(None, n_total=n, group=dist.group.WORLD, engine=eng)
+        idx, sc = sh.query(Q, k, metric_id)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), idx=idx, sc=sc, exact_calls=eng.exact_calls, lo=lo, hi=hi)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("metric_id,fail_rank", [(1, None), (0, 1), (3, None)])
+def test_two_rank_gloo_matches_global(tmp_path, metric_id, fail_rank):
+    from oracle import ranking_oracle as orc
+    world, n, d, k = 2, 1000, 24, 10
+    port = 29500 + (os.getpid() % 2000) + metric_id
+    mp.spawn(_worker, args=(world, port, n, d, k, metric_id, fail_rank, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(77)
+    V = rng.standard_normal((n, d)).astype(np.float32)
+    V[n // 2 + 3] = V[5]
+    Q = rng.standard_normal((4, d)).astype(np.float32)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert (int(r0["lo"]), int(r0["hi"]), int(r1["lo"]), int(r1["hi"])) == (0, 496, 496, 1000)
+    assert np.array_equal(r0["idx"], r1["idx"]) and np.array_equal(r0["sc"], r1["sc"]), "ranks must agree"
+    for qi in range(4):
+        ex = orc.exact_scores(V, Q[qi], METRICS[metric_id]).astype(np.float32)
+        want = np.lexsort((np.arange(n), -ex))[:k]
+        assert np.array_equal(r0["idx"][qi], want), (qi, r0["idx"][qi], want)
+        assert np.array_equal(r0["sc"][qi], ex[want])
+    # a failed threshold on ONE rank triggers the exact re-run on BOTH (collective consistency)
+    expect_exact = 1 if fail_rank is not None else 0
+    assert int(r0["exact_calls"]) == expect_exact and int(r1["exact_calls"]) == expect_exact
+
+
+def test_shard_bounds_cover_everything():
+    from hyperdb.sharded import shard_bounds
+    for n, w, g in [(10_000_000, 8, 250_000), (1000, 3, 16), (7, 4, 1), (100_000_000, 8, 250_000)]:
+        b = shard_bounds(n, w, g)
+        assert b[0][0] == 0 and b[-1][1] == n
+        assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+        assert all(lo % g == 0 for lo, _ in b)
