@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--batch-steps", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=200_000)
+    ap.add_argument("--extra", default="", help="comma list of extra BASELINE configs to time after the headline: c2,c5")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run")
     return ap.parse_args()
@@ -108,6 +109,49 @@ def cpu_baseline(args, V_dev, Q_dev):
     }
 
 
+def extra_leg(name, device):
+    """Other BASELINE.json configs, single GPU: returns a dict for the JSON line."""
+    from hyperdb._native import GpuIndex, METRIC_IDS
+    if name == "c2":      # N=1M d=384 fp32 single-query cosine top-100 (HBM-bound GEMV path)
+        n, d, dt, elem, q, metric, steps, bias = 1_000_000, 384, torch.float32, 4, 1, "cosine_similarity", 200, False
+    elif name == "c5":    # N=10M d=768 fp16 euclidean + time-decay re-rank, batch-Q=64
+        n, d, dt, elem, q, metric, steps, bias = 10_000_000, 768, torch.float16, 2, 64, "euclidean_metric", 10, True
+    else:
+        raise SystemExit(f"unknown extra config {name}")
+    V, lo, hi = make_shard(n, d, dt, 0, 1, device)
+    ix = GpuIndex(V, device=device)
+    if bias:
+        g = torch.Generator(device=device).manual_seed(99)
+        ts = 1.7e9 + torch.rand(n, generator=g, device=device, dtype=torch.float64) * 30 * 86400.0
+        ix.set_recency(ts, 0.5)
+    Q = make_queries(q * 4, d, dt, device)
+    mid = METRIC_IDS[metric]
+    for i in range(3):
+        ix.topk(Q[:q], 100, mid)
+    ix.set_option("profile", 1)
+    torch.cuda.synchronize()
+    lat = []
+    t0 = time.perf_counter()
+    for i in range(steps):
+        t1 = time.perf_counter()
+        ix.topk(Q[(i % 4) * q:(i % 4 + 1) * q], 100, mid)
+        lat.append(time.perf_counter() - t1)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    ns, nl = ix.stat("scan_time_ns"), ix.stat("scan_launches")
+    kern_s = ns * 1e-9 / max(nl, 1)
+    alg = n * d * elem
+    out = {"config": name, "workload": f"N={n} d={d} {'fp32' if elem == 4 else 'fp16'} Q={q} {metric}{' + recency bias' if bias else ''} top-100",
+           "qps": q * steps / el, "ms_per_call": 1e3 * el / steps, "p50_ms": 1e3 * float(np.median(lat)),
+           "kernel_us": kern_s * 1e6, "mfma_path": bool(ix.stat("mfma")),
+           "roofline": {"bound": "hbm", "achieved": alg / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": alg / kern_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg}}
+    ix.close()
+    del V
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,7 +163,7 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("HDB_FORCE_DIST") == "1":     # HDB_FORCE_DIST: exercise the RCCL path on one GPU
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -132,7 +176,8 @@ def main():
     elem = 2 if args.dtype == "fp16" else 4
     V, lo, hi = make_shard(args.n, args.d, tdtype, rank, world, device)
     local = GpuIndex(V, device=device, row_base=lo)
-    sharded = ShardedIndex(local, n_total=args.n, group=(dist.group.WORLD if dist else None))
+    sharded = ShardedIndex(local, n_total=args.n, group=(dist.group.WORLD if dist else None),
+                           force_exchange=os.environ.get("HDB_FORCE_DIST") == "1")
     Q = make_queries(max(args.steps + args.warmup, 1), args.d, tdtype, device)
     mid = METRIC_IDS[args.metric]
     torch.cuda.synchronize()
@@ -202,9 +247,30 @@ def main():
                              "frac": alg_bytes / per_batch_kernel_s / 1e9 / HBM_PEAK_GBS if per_batch_kernel_s else 0.0},
         }
 
+    # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (counters cannot be read
+    # inside this process); the corrected per-launch figure is committed under profiles/ by profiles/summarize.py
+    traffic = args.pmc_traffic
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if traffic is None and os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            key = f"n={hi - lo},d={args.d},{args.dtype},q=1,{args.metric}"
+            if key in tj:
+                traffic = tj[key]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, V, Q)
+
+    extras = []
+    if rank == 0 and world == 1 and args.extra:
+        local.close()
+        del sharded, local, V
+        torch.cuda.empty_cache()
+        for name in [x for x in args.extra.split(",") if x]:
+            extras.append(extra_leg(name, device))
 
     if rank == 0:
         out = {
@@ -217,12 +283,14 @@ def main():
             "config": {"workload": f"N={args.n} d={args.d} {args.dtype} Q=1 {args.metric} top-{args.k}, row-sharded x{world}",
                        "rows_per_gpu": hi - lo, "exchange": "none" if world == 1 else "1 RCCL all-gather of packed top-k per query"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": args.pmc_traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "hdb_scan_kernel (filter pass over all rows)", "kernel_us": kern_s * 1e6,
                          "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": scan_launches},
             "cpu_baseline": cpu,
             "batched": batched,
         }
+        if extras:
+            out["extra"] = extras
         print(json.dumps(out))
     if dist:
         dist.destroy_process_group()

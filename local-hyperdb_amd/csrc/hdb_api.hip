@@ -43,6 +43,8 @@ int hdb_mfma_tile_rows(int d);
 int hdb_launch_mfma_scan(const ScanArgs* args, int mode, int nq_launch, const void* q16, const float* sqnorm,
                          const float* qsq, int max_blocks, void* stream);
 int hdb_launch_q_to_f16(const float* Q, int nq, int d, void* q16, void* stream);
+int hdb_launch_rescore_euclid(unsigned long long* cand, const uint32_t* cnt, uint32_t cap, int nq_launch, const void* V, int d,
+                              const float* Q, int q0, const float* bias, void* stream);
 }
 
 static thread_local std::string g_err;
@@ -457,6 +459,8 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
             for (int p = 0; p < 4; ++p) LAUNCH_TRY(hdb_launch_hist(sbuf, n, ld_n, cq, hist, p, kk, st));
             LAUNCH_TRY(hdb_launch_collect(sbuf, n, ld_n, cq, hist, kk, cnt, cand, HDB_CAND_CAP, tie_info, st));
         }
+        if (mfma && metric == HDB_EUCLIDEAN)     // the MFMA path scores through ||v||^2+||q||^2-2v.q: redo near-duplicates directly
+            LAUNCH_TRY(hdb_launch_rescore_euclid(cand, cnt, HDB_CAND_CAP, cq, ix->V, ix->d, (const float*)dev_Q, q0, ix->bias, st));
         LAUNCH_TRY(hdb_launch_finalize(cand, cnt, HDB_CAND_CAP, cq, (uint32_t)k, kk, ix->row_base,
                                        dev_idx + (int64_t)q0 * k, dev_score + (int64_t)q0 * k,
                                        dev_status ? dev_status + q0 : nullptr, qnan + q0, st));

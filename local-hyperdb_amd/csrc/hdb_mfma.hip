@@ -1,27 +1,31 @@
 // hdb_mfma.hip -- batched Q.V^T scan on the gfx950 matrix cores (fp16 data, fp32 accumulate).
 //
-// Replaces "np.dot(vectors, query.T)" (hyperdb/ranking_algorithm.py:29,:41) for a batch of queries:
-// the reference takes one query per call; here up to 256 queries ride on ONE pass over V.
+// Replaces "np.dot(vectors, query.T)" (hyperdb/ranking_algorithm.py:29,:41) and, through
+// ||v-q||^2 = ||v||^2 + ||q||^2 - 2 v.q, "np.linalg.norm(vectors - query, axis=1)" (:49) for a batch of
+// queries: the reference takes one query per call; here up to 8*MF queries ride on ONE pass over V.
 //
 // Work decomposition (one workgroup = 8 waves = 512 threads, one workgroup per CU, persistent):
-//   * wave w owns queries [32w, 32w+32) of the batch; their fp16 values for ALL k live in its
-//     registers as MFMA B fragments (D/16 fragments x 4 VGPRs = 96 VGPRs at d=384), loaded once;
+//   * wave w owns MF queries of the batch (MF = 32: v_mfma_f32_32x32x16_f16, MF = 16:
+//     v_mfma_f32_16x16x32_f16); their fp16 values for ALL k live in its registers as MFMA B fragments
+//     (d/8 VGPRs for MF=16, d/4 for MF=32), loaded once;
 //   * the workgroup streams tiles of R rows of V through a 3-deep LDS ring filled by LDS-DMA
 //     (global_load_lds_dwordx4, 1 KiB per wave-instruction, source-side XOR swizzle so that the
-//     lane-linear LDS image is bank-conflict-free for the ds_read_b128 A-fragment reads);
-//   * every wave multiplies the whole tile by its 32 queries: v_mfma_f32_32x32x16_f16, one
-//     ds_read_b128 per MFMA, accumulators never leave registers;
-//   * epilogue in registers: scale / bias / threshold compare; survivors go to a small LDS list
-//     that is flushed to the per-query candidate lists with global atomics every few hundred tiles.
-//     The N x Q score matrix is never written (10 GB at N=10M, Q=256).
-// Synchronisation: one raw s_barrier per tile; tile t+2 is in flight while tile t is multiplied
-// (counted s_waitcnt vmcnt, never 0 in the steady state).
-// Algorithmic bytes per row: d*2 (V read exactly once per 256 queries); FLOPs: 2*Q*d per row.
+//     lane-linear LDS image is bank-conflict-free for the ds_read_b128 A-fragment reads), together with
+//     the per-row aux values (1/||v|| or ||v||^2, bias);
+//   * every wave multiplies the whole tile by its queries, one ds_read_b128 per MFMA, issued two k-steps
+//     ahead from inline asm with counted lgkmcnt waits; accumulators never leave registers;
+//   * epilogue in registers: scale / bias / threshold compare behind a group-max prefilter; survivors go
+//     to a small LDS list that is flushed to the per-query candidate lists with global atomics every few
+//     hundred tiles.  The N x Q score matrix is never written (10 GB at N=10M, Q=256).
+// Synchronisation: one raw s_barrier per tile; tile t+2 is in flight while tile t is multiplied (counted
+// s_waitcnt vmcnt, never 0 in the steady state); LDS-DMA pieces are issued between the MFMAs.
+// Algorithmic bytes per row: d*2 (V read exactly once per pass); FLOPs: 2*Q*d per row.
 #include "hdb_common.h"
 #include "../../include/hyperdb_hip.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define HDB_MFMA_CB 1024            // LDS candidate list entries per workgroup
 
@@ -30,15 +34,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int N> __device__ __forceinline__ void hdb_wait_vmcnt() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if constexpr (N == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-    else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
     else static_assert(N < 0, "add this vmcnt immediate");
 }
 __device__ __forceinline__ unsigned long long hdb_stamp() {
@@ -56,19 +59,38 @@ __device__ __forceinline__ void hdb_lds_barrier() {
     __builtin_amdgcn_s_barrier();
 }
 
+template <int MF> struct MfmaShape;
+template <> struct MfmaShape<32> {
+    using Acc = f32x16;
+    static constexpr int KSTEP = 16, NGRP = 4;      // k per MFMA; groups of 4 consecutive rows per lane per tile
+    __device__ static __forceinline__ Acc mma(half8 a, half8 b, Acc c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct MfmaShape<16> {
+    using Acc = f32x4;
+    static constexpr int KSTEP = 32, NGRP = 1;
+    __device__ static __forceinline__ Acc mma(half8 a, half8 b, Acc c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+
 // METRIC: 0 dot, 1 cosine (aux0 = 1/||v||), 2 euclidean similarity (aux0 = ||v||^2)
-template <int D, int R, int MODE, int METRIC, bool HAS_BIAS>
+// Fragment maps (lane l):  MF=32: row/query l&31, k = 16s + 8(l>>5) + j, C reg e -> row (e&3) + 8(e>>2) + 4(l>>5)
+//                          MF=16: row/query l&15, k = 32s + 8(l>>4) + j, C reg e -> row 4(l>>4) + e
+template <int MF, int D, int R, int MODE, int METRIC, bool HAS_BIAS>
 __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float16* __restrict__ q16,
                                                        const float* __restrict__ aux0g, const float* __restrict__ qsq,
                                                        int nq_end) {
+    using Shape = MfmaShape<MF>;
+    using Acc = typename Shape::Acc;
+    constexpr int KSTEP = Shape::KSTEP, NGRP = Shape::NGRP;
     constexpr int CPR = D / 8;                  // 16-byte chunks per row
-    constexpr int KS = D / 16;                  // k-steps of v_mfma_f32_32x32x16_f16
-    constexpr int RT = R / 32;                  // 32-row MFMA tiles per stage
+    constexpr int KS = D / KSTEP;               // MFMA k-steps
+    constexpr int CPS = KSTEP / 8;              // chunks per k-step (2 or 4)
+    constexpr int RT = R / MF;                  // MFMA row tiles per stage
     constexpr int STAGE = R * D * 2;            // bytes of V per stage
     constexpr int NG = R * CPR / 64 / 8;        // LDS-DMA instructions per wave per tile
     constexpr bool AUX0 = METRIC != 0;
-    constexpr int NLOAD = NG + (AUX0 ? 1 : 0) + (HAS_BIAS ? 1 : 0);
-    static_assert(R % 32 == 0 && (R * CPR) % 512 == 0 && D % 128 == 0, "tile geometry");
+    constexpr int NLOADA = NG;
+    constexpr int NLOADB = NG + (AUX0 ? 1 : 0) + (HAS_BIAS ? 1 : 0);     // B waves also stage the per-row aux values
+    static_assert(R % MF == 0 && R <= 64 && (R * CPR) % 512 == 0 && D % 128 == 0 && KS % NG == 0, "tile geometry");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* auxbuf = reinterpret_cast<float*>(smem + 3 * STAGE);                    // [3 stages][2][64]
@@ -78,12 +100,13 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r31 = lane & 31, h = lane >> 5;
+    const int rl = lane & (MF - 1);             // row of the A fragment == query of the B fragment
+    const int h = lane / MF;                    // which 8-element k-chunk of the step (0..CPS-1)
 
     // ---- this wave's queries --------------------------------------------------------------------
-    const int qw0 = a.q0 + blockIdx.y * 256 + w * 32;
+    const int qw0 = a.q0 + blockIdx.y * (8 * MF) + w * MF;
     const bool wave_active = qw0 < nq_end;
-    const int q = qw0 + r31;
+    const int q = qw0 + rl;
     const bool q_ok = q < nq_end;
     const int ql = q - a.q0;
     half8 Bq[KS];
@@ -92,7 +115,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
         const uint4* src = reinterpret_cast<const uint4*>(q16 + (int64_t)qq * D + 8 * h);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            uint4 v = src[2 * s];
+            uint4 v = src[CPS * s];
             if (!q_ok) v = make_uint4(0, 0, 0, 0);
             Bq[s] = *reinterpret_cast<half8*>(&v);
         }
@@ -106,14 +129,10 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
     if (tid < 4) ctl[tid] = 0;
 
     // ---- roles ----------------------------------------------------------------------------------------
-    // Waves 0-3 ("A") and 4-7 ("B") are the two waves of each SIMD.  An LDS-DMA instruction costs its wave
-    // ~90 issue cycles (48 of them per tile), so the staging of tile i+2 is split: B issues its half at the
-    // START of interval i and runs its threshold epilogue one tile late, A (raised priority) owns the
-    // matrix pipe first and issues its half at the END, while B multiplies.  Without this split both waves
-    // of a SIMD reach DMA issue, MFMA, epilogue and barrier together and the matrix pipe idles ~40 %.
+    // Waves 0-3 ("A") and 4-7 ("B") are the two waves of each SIMD.  B runs its threshold epilogue one tile
+    // late (while A, at raised priority, owns the matrix pipe) so that the two waves of a SIMD do not reach
+    // MFMA phase, epilogue and barrier in lock-step.
     const bool grpB = w >= 4;
-    constexpr int NLOADA = NG;
-    constexpr int NLOADB = NG + (AUX0 ? 1 : 0) + (HAS_BIAS ? 1 : 0);     // B also stages the per-row aux values
 
     // ---- staging geometry (per lane, fixed for the whole kernel) -----------------------------------
     int g_off[NG];
@@ -178,10 +197,12 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
     const unsigned int ctl_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(ctl);
     const unsigned int cb_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(cb);
     const unsigned int cbq_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(cbq);
-    // per-lane LDS read address: row r31 of a 32-row tile; chunk (2s+h)^rx of k-step s is at
-    // byte (32s ^ hx) of the row image, hx = (h ^ rx) << 4  (2s and h occupy disjoint bits)
-    const unsigned int rd_base = (unsigned int)(r31 * CPR * 16);
-    const unsigned int hx = (unsigned int)((h ^ (r31 & 15)) << 4);
+    // per-lane LDS read address: row rl of a row tile; chunk (CPS*s + h) ^ rx of k-step s is at byte
+    // ((16*CPS*s) ^ hx) of the row image, hx = (h ^ rx) << 4  (CPS*s and h occupy disjoint bits)
+    const unsigned int rd_base = (unsigned int)(rl * CPR * 16);
+    const unsigned int hx = (unsigned int)((h ^ (rl & 15)) << 4);
+    // first of the 4 consecutive tile rows this lane's accumulator group g holds
+    auto grp_row = [&](int rt, int g) { return MF == 32 ? rt * 32 + 8 * g + 4 * h : rt * 16 + 4 * h; };
 
     // threshold in the domain the epilogue compares in (see below); +inf for padding lanes
     float thr_cmp = INFINITY;
@@ -192,25 +213,25 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
 
     // Filter, second half: group maxima (v_max3) let the common no-hit case finish in ~25 VALU
     // instructions; survivors go to the workgroup's LDS list.  `tv` holds comparable values (below).
-    auto filter = [&](const f32x16 (&tv)[RT], int64_t row0) {
-        float gm[RT][4];
+    auto filter = [&](const Acc (&tv)[RT], int64_t row0) {
+        float gm[RT][NGRP];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+            for (int g = 0; g < NGRP; ++g)
                 gm[rt][g] = fmaxf(fmaxf(tv[rt][4 * g], tv[rt][4 * g + 1]), fmaxf(tv[rt][4 * g + 2], tv[rt][4 * g + 3]));
         float m = gm[0][0];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) m = fmaxf(m, gm[rt][g]);
+            for (int g = 0; g < NGRP; ++g) m = fmaxf(m, gm[rt][g]);
         if (m >= thr_cmp) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
+                for (int g = 0; g < NGRP; ++g) {
                     if (gm[rt][g] >= thr_cmp) {
-                        const int64_t rowg = row0 + rt * 32 + 8 * g + 4 * h;
+                        const int64_t rowg = row0 + grp_row(rt, g);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float x = tv[rt][4 * g + j];
@@ -236,7 +257,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
         }
     };
 
-    f32x16 acc[RT];
+    Acc acc[RT];
     int64_t row0_prev = 0;
     int st_cur = 0;
     // diagnostic stamps (dbg & 8, timing study only): block 0, lane 0 of waves 0 and 4, first 64 tiles,
@@ -272,46 +293,52 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) acc[rt][e] = 0.f;
+                for (int e = 0; e < 4 * NGRP; ++e) acc[rt][e] = 0.f;
 
-            // A fragments: LDS reads issued one k-step ahead of the MFMAs that consume them.  The reads
+            // A fragments: LDS reads issued two k-steps ahead of the MFMAs that consume them.  The reads
             // and their counted waits are inline asm so that hipcc cannot sink a read next to its use
-            // (it otherwise emits read, lgkmcnt(0), MFMA per step and exposes the LDS latency 24 times).
-            // lgkmcnt(RT) = "all but the RT newest LDS ops are back" = the previous step's fragments;
+            // (it otherwise emits read, lgkmcnt(0), MFMA per step and exposes the LDS latency every step).
+            // lgkmcnt(n*RT) = "all but the n*RT newest LDS ops are back" = the oldest pending step's fragments;
             // stray scalar loads can only make that wait longer, never shorter.
             const unsigned int sb_addr = smem_addr + (unsigned int)(st_cur * STAGE) + rd_base;
             half8 abuf[3][RT];
             auto fetch = [&](int s, half8 (&dst)[RT]) {
-                const unsigned int ad = sb_addr + ((unsigned int)(32 * s) ^ hx);
+                const unsigned int ad = sb_addr + ((unsigned int)(16 * CPS * s) ^ hx);
                 asm volatile("ds_read_b128 %0, %1" : "=v"(dst[0]) : "v"(ad));
-                if constexpr (RT > 1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[1]) : "v"(ad), "i"(32 * CPR * 16));
+                if constexpr (RT > 1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[1]) : "v"(ad), "i"(MF * CPR * 16));
+                if constexpr (RT > 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[2]) : "v"(ad), "i"(2 * MF * CPR * 16));
+                if constexpr (RT > 3) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[3]) : "v"(ad), "i"(3 * MF * CPR * 16));
             };
             auto wait_frag = [&](int pending_steps, half8 (&f)[RT]) {     // fragments of the oldest step are back
-                if constexpr (RT > 1) {
+                static_assert(RT == 1 || RT == 2 || RT == 4, "RT");
+                if constexpr (RT == 1) {
+                    if (pending_steps == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(f[0]));
+                    else if (pending_steps == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(f[0]));
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]));
+                } else if constexpr (RT == 2) {
                     if (pending_steps == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f[0]), "+v"(f[1]));
                     else if (pending_steps == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(f[0]), "+v"(f[1]));
                     else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]));
                 } else {
-                    if (pending_steps == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(f[0]));
-                    else if (pending_steps == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(f[0]));
-                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]));
+                    if (pending_steps == 2) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
+                    else if (pending_steps == 1) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
+                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
                 }
             };
             if (!grpB && !(a.dbg & 16)) __builtin_amdgcn_s_setprio(2);
             if (!(a.dbg & 2)) {
-            fetch(0, abuf[0]);
-            if (KS > 1) fetch(1, abuf[1]);
+                fetch(0, abuf[0]);
+                if (KS > 1) fetch(1, abuf[1]);
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                if (s + 2 < KS) fetch(s + 2, abuf[(s + 2) % 3]);
-                wait_frag(s + 2 < KS ? 2 : (s + 1 < KS ? 1 : 0), abuf[s % 3]);
+                for (int s = 0; s < KS; ++s) {
+                    if (s + 2 < KS) fetch(s + 2, abuf[(s + 2) % 3]);
+                    wait_frag(s + 2 < KS ? 2 : (s + 1 < KS ? 1 : 0), abuf[s % 3]);
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-                    acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(abuf[s % 3][rt], Bq[s], acc[rt], 0, 0, 0);
-                // LDS-DMA pieces of tile i+2 ride between the MFMAs: one every KS/NG k-steps
-                constexpr int EVERY = KS / NG;
-                if (s % EVERY == EVERY / 2 && s / EVERY < NG) { if (more) issue_piece(i + 2, st_next2, s / EVERY); }
-            }
+                    for (int rt = 0; rt < RT; ++rt) acc[rt] = Shape::mma(abuf[s % 3][rt], Bq[s], acc[rt]);
+                    // LDS-DMA pieces of tile i+2 ride between the MFMAs: one every KS/NG k-steps
+                    constexpr int EVERY = KS / NG;
+                    if (s % EVERY == EVERY / 2 && s / EVERY < NG) { if (more) issue_piece(i + 2, st_next2, s / EVERY); }
+                }
             } else if (more) {
 #pragma unroll
                 for (int j = 0; j < NG; ++j) issue_piece(i + 2, st_next2, j);
@@ -319,17 +346,17 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
             if (!grpB) __builtin_amdgcn_s_setprio(0);
             HDB_STAMP(5);
 
-            // ---- epilogue, first half: lane holds query q and rows rt*32 + 8g + 4h + j (register 4g+j).
-            // Turn the dot products into the values that are stored (MODE 0) or compared (MODE 1), in place.
-            // Filter mode compares the score itself, except cosine without bias: dot/||v|| vs thr/qinv.
+            // ---- epilogue, first half: turn the dot products into the values that are stored (MODE 0) or
+            // compared (MODE 1), in place.  Filter mode compares the score itself, except cosine without
+            // bias: dot/||v|| against thr/qinv (one multiply per score).
             const float* ax0 = auxbuf + (st_cur * 2 + 0) * 64;
             const float* ax1 = auxbuf + (st_cur * 2 + 1) * 64;
             if (METRIC != 0 || HAS_BIAS) {
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int rl0 = rt * 32 + 8 * g + 4 * h;
+                    for (int g = 0; g < NGRP; ++g) {
+                        const int rl0 = grp_row(rt, g);
                         float4 av = make_float4(1.f, 1.f, 1.f, 1.f), bv = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (AUX0) av = *reinterpret_cast<const float4*>(ax0 + rl0);
                         if (HAS_BIAS) bv = *reinterpret_cast<const float4*>(ax1 + rl0);
@@ -356,8 +383,8 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int rl0 = rt * 32 + 8 * g + 4 * h;
+                    for (int g = 0; g < NGRP; ++g) {
+                        const int rl0 = grp_row(rt, g);
                         const int64_t rowg = row0 + rl0;
                         float sj[4];
 #pragma unroll
@@ -394,14 +421,40 @@ __global__ void hdb_q_to_f16_kernel(const float* Q, int64_t count, _Float16* out
     if (i < count) out[i] = (_Float16)Q[i];
 }
 
+// Euclidean scores from the MFMA path come from ||v||^2 + ||q||^2 - 2 v.q, which cancels when v ~ q (an
+// exact duplicate scores 1/(1+~0.01) instead of 1).  Candidates whose similarity exceeds 0.5 (distance < 1)
+// are re-scored from the stored row with the direct difference, like the reference (:49).  One wave per entry.
+template <bool HAS_BIAS>
+__global__ __launch_bounds__(256) void hdb_rescore_euclid_kernel(unsigned long long* cand, const uint32_t* cnt, uint32_t cap,
+                                                                 const _Float16* V, int d, const float* Q, int q0,
+                                                                 const float* bias) {
+    const int ql = blockIdx.y, lane = threadIdx.x & 63;
+    const uint32_t n = cnt[ql] < cap ? cnt[ql] : cap;
+    const float* qv = Q + (int64_t)(q0 + ql) * d;
+    for (uint32_t e = blockIdx.x * 4 + (threadIdx.x >> 6); e < n; e += gridDim.x * 4) {
+        const unsigned long long ent = cand[(int64_t)ql * cap + e];
+        const uint32_t row = 0xFFFFFFFFu - (uint32_t)(ent & 0xFFFFFFFFull);
+        float s = hdb_key2f((uint32_t)(ent >> 32));
+        const float b = HAS_BIAS ? bias[row] : 0.f;
+        if (s - b > 0.5f) {                                        // wave-uniform: one entry per wave
+            float acc = 0.f;
+            for (int k = lane; k < d; k += 64) { const float df = (float)V[(int64_t)row * d + k] - qv[k]; acc += df * df; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+            s = hdb_canon(1.f / (1.f + sqrtf(acc)) + b);
+            if (lane == 0) cand[(int64_t)ql * cap + e] = hdb_pack(s, row);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 static size_t mfma_lds_bytes(int stage_bytes) {
     return (size_t)3 * stage_bytes + 3 * 2 * 64 * 4 + (size_t)HDB_MFMA_CB * 8 + (size_t)HDB_MFMA_CB * 2 + 64;
 }
 
-template <int D, int R, int MODE, int METRIC, bool HAS_BIAS>
+template <int MF, int D, int R, int MODE, int METRIC, bool HAS_BIAS>
 static int launch_one(const ScanArgs& a, const void* q16, const float* aux0, const float* qsq, int nq_launch, int blocks, hipStream_t st) {
-    auto kern = hdb_mfma_kernel<D, R, MODE, METRIC, HAS_BIAS>;
+    auto kern = hdb_mfma_kernel<MF, D, R, MODE, METRIC, HAS_BIAS>;
     const size_t lds = mfma_lds_bytes(R * D * 2);
     static bool attr_done = false;          // per instantiation
     if (!attr_done) {
@@ -409,29 +462,46 @@ static int launch_one(const ScanArgs& a, const void* q16, const float* aux0, con
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    const dim3 grid(blocks, (nq_launch + 255) / 256);
+    const dim3 grid(blocks, (nq_launch + 8 * MF - 1) / (8 * MF));
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a, (const _Float16*)q16, aux0, qsq, a.q0 + nq_launch);
     return (int)hipGetLastError();
 }
 
-template <int D, int R, int MODE, int METRIC>
-static int launch_bias(const ScanArgs& a, const void* q16, const float* aux0, const float* qsq, int nq_launch, int blocks, hipStream_t st) {
-    if (a.bias) return launch_one<D, R, MODE, METRIC, true>(a, q16, aux0, qsq, nq_launch, blocks, st);
-    return launch_one<D, R, MODE, METRIC, false>(a, q16, aux0, qsq, nq_launch, blocks, st);
-}
-
-template <int D, int R, int MODE>
+template <int MF, int D, int R, int MODE>
 static int launch_metric(const ScanArgs& a, const void* q16, const float* sqnorm, const float* qsq, int nq_launch, int blocks, hipStream_t st) {
-    if (a.metric == HDB_DOT) return launch_bias<D, R, MODE, 0>(a, q16, nullptr, qsq, nq_launch, blocks, st);
-    if (a.metric == HDB_COSINE) return launch_bias<D, R, MODE, 1>(a, q16, a.inv_norm, qsq, nq_launch, blocks, st);
+    const bool b = a.bias != nullptr;
+    if (a.metric == HDB_DOT) return b ? launch_one<MF, D, R, MODE, 0, true>(a, q16, nullptr, qsq, nq_launch, blocks, st)
+                                      : launch_one<MF, D, R, MODE, 0, false>(a, q16, nullptr, qsq, nq_launch, blocks, st);
+    if (a.metric == HDB_COSINE) return b ? launch_one<MF, D, R, MODE, 1, true>(a, q16, a.inv_norm, qsq, nq_launch, blocks, st)
+                                         : launch_one<MF, D, R, MODE, 1, false>(a, q16, a.inv_norm, qsq, nq_launch, blocks, st);
+    if (a.metric == HDB_EUCLIDEAN) return b ? launch_one<MF, D, R, MODE, 2, true>(a, q16, sqnorm, qsq, nq_launch, blocks, st)
+                                            : launch_one<MF, D, R, MODE, 2, false>(a, q16, sqnorm, qsq, nq_launch, blocks, st);
     return (int)hipErrorNotSupported;
 }
 
-extern "C" int hdb_mfma_tile_rows(int d) { return d == 384 ? 64 : 0; }
+template <int MF, int D, int R>
+static int launch_mode(const ScanArgs& a, int mode, const void* q16, const float* sqnorm, const float* qsq, int nq_launch, int blocks, hipStream_t st) {
+    if (mode == 0) return launch_metric<MF, D, R, 0>(a, q16, sqnorm, qsq, nq_launch, blocks, st);
+    return launch_metric<MF, D, R, 1>(a, q16, sqnorm, qsq, nq_launch, blocks, st);
+}
+
+// Geometry table: rows per LDS stage (stage = R*d*2 bytes <= 48 KiB, three stages + lists <= 160 KiB).
+// d=384 with more than 128 queries uses the 32x32x16 shape (256 queries per pass); everything else the
+// 16x16x32 shape (128 queries per pass, B fragments d/8 VGPRs).
+extern "C" int hdb_mfma_tile_rows(int d) {
+    switch (d) {
+        case 128: case 256: case 384: return 64;
+        case 512: case 640: case 768: return 32;
+        default: return 0;
+    }
+}
 
 extern "C" int hdb_mfma_supported(int dtype, int d, int metric) {
-    return dtype == HDB_F16 && hdb_mfma_tile_rows(d) > 0 && (metric == HDB_DOT || metric == HDB_COSINE);
+    return dtype == HDB_F16 && hdb_mfma_tile_rows(d) > 0 &&
+           (metric == HDB_DOT || metric == HDB_COSINE || metric == HDB_EUCLIDEAN);
 }
+
+extern "C" int hdb_mfma_queries_per_pass(int d, int nq) { return (d == 384 && nq > 128) ? 256 : 128; }
 
 // a.ntiles / a.tile_stride are in units of hdb_mfma_tile_rows(d) rows here.
 extern "C" int hdb_launch_mfma_scan(const ScanArgs* args, int mode, int nq_launch, const void* q16, const float* sqnorm,
@@ -442,15 +512,29 @@ extern "C" int hdb_launch_mfma_scan(const ScanArgs* args, int mode, int nq_launc
     int blocks = (int)(a.ntiles < 256 ? a.ntiles : 256);
     if (max_blocks > 0 && max_blocks < blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
-    if (a.d == 384) {
-        if (mode == 0) return launch_metric<384, 64, 0>(a, q16, sqnorm, qsq, nq_launch, blocks, st);
-        return launch_metric<384, 64, 1>(a, q16, sqnorm, qsq, nq_launch, blocks, st);
+    switch (a.d) {
+        case 128: return launch_mode<16, 128, 64>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
+        case 256: return launch_mode<16, 256, 64>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
+        case 384:
+            if (nq_launch > 128) return launch_mode<32, 384, 64>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
+            return launch_mode<16, 384, 64>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
+        case 512: return launch_mode<16, 512, 32>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
+        case 640: return launch_mode<16, 640, 32>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
+        case 768: return launch_mode<16, 768, 32>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
+        default: return (int)hipErrorNotSupported;
     }
-    return (int)hipErrorNotSupported;
 }
 
 extern "C" int hdb_launch_q_to_f16(const float* Q, int nq, int d, void* q16, void* stream) {
     const int64_t count = (int64_t)nq * d;
     hipLaunchKernelGGL(hdb_q_to_f16_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Q, count, (_Float16*)q16);
+    return (int)hipGetLastError();
+}
+
+extern "C" int hdb_launch_rescore_euclid(unsigned long long* cand, const uint32_t* cnt, uint32_t cap, int nq_launch, const void* V,
+                                         int d, const float* Q, int q0, const float* bias, void* stream) {
+    const dim3 grid(64, nq_launch);
+    if (bias) hipLaunchKernelGGL(hdb_rescore_euclid_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, cand, cnt, cap, (const _Float16*)V, d, Q, q0, bias);
+    else hipLaunchKernelGGL(hdb_rescore_euclid_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, cand, cnt, cap, (const _Float16*)V, d, Q, q0, bias);
     return (int)hipGetLastError();
 }

@@ -483,3 +483,43 @@ def test_mfma_with_recency_bias(orc):
         orc.check_topk(mi[0].cpu().numpy(), ms[0].cpu().numpy(), V, Q[0], "cosine_similarity", k, bias=bias, tol=1e-3)
     finally:
         ix.close()
+
+
+@pytest.mark.parametrize("d,nq,metric,bias", [(768, 64, "euclidean_metric", True), (768, 64, "cosine_similarity", False),
+                                              (128, 40, "dot_product", False), (256, 128, "euclidean_metric", False),
+                                              (512, 33, "cosine_similarity", True), (640, 16, "dot_product", True),
+                                              (384, 96, "euclidean_metric", True)])
+def test_mfma_shapes_and_euclidean(orc, d, nq, metric, bias):
+    """Config-5 shaped case (d=768, Q=64, euclidean + time decay) and the other MFMA geometries."""
+    import torch
+    from hyperdb._native import GpuIndex, METRIC_IDS
+    rng = np.random.default_rng(d + nq)
+    n, k = 60_000 + 17, 50
+    V = rng.standard_normal((n, d)).astype(np.float32).astype(np.float16)
+    Q = rng.standard_normal((nq, d)).astype(np.float16)
+    Q[0] = V[n - 5]                                   # exact duplicate: euclidean similarity must come out as 1.0
+    Q[1] = (V[123].astype(np.float32) + 0.01 * rng.standard_normal(d)).astype(np.float16)   # near duplicate
+    ts = 1.7e9 + rng.uniform(0, 30 * 86400.0, size=n)
+    ix = GpuIndex(V)
+    try:
+        b = None
+        if bias:
+            ix.set_recency(ts, 0.5)
+            b = 0.5 * np.exp(ts - ts.max())
+        mid = METRIC_IDS[metric]
+        mi, ms, mst = ix.topk_device(Q, k, mid)
+        assert ix.stat("mfma") == 1 and ix.stat("path") == 1
+        assert int(mst.abs().sum().item()) == 0
+        ix.set_option("use_mfma", 0)
+        vi, vs, _ = ix.topk_device(Q, k, mid)
+        ix.set_option("use_mfma", 1)
+        mi_h, ms_h, vi_h, vs_h = mi.cpu().numpy(), ms.cpu().numpy(), vi.cpu().numpy(), vs.cpu().numpy()
+        for qi in range(nq):
+            assert orc.same_result_modulo_ties(mi_h[qi], ms_h[qi], vi_h[qi], vs_h[qi], 2e-5), qi
+        for qi in (0, 1, nq - 1):
+            orc.check_topk(mi_h[qi], ms_h[qi], V, Q[qi], metric, k, bias=b, tol=1e-3)
+        if metric == "euclidean_metric" and not bias:
+            assert mi_h[0][0] == n - 5 and abs(ms_h[0][0] - 1.0) < 1e-6, "exact duplicate must score exactly 1"
+            assert mi_h[1][0] == 123
+    finally:
+        ix.close()
