@@ -37,6 +37,8 @@ int hdb_launch_finalize(const unsigned long long* cand, const uint32_t* cnt, uin
 int hdb_launch_merge(const void* idx_base, int64_t idx_stride, const void* score_base, int64_t score_stride,
                      const void* status_base, int64_t status_stride, int parts, int nq, uint32_t k, int64_t* idx_out,
                      float* score_out, int32_t* status_out, void* stream);
+int hdb_launch_rowstats(const void* V, int64_t n, int d, int dtype, float* pscale, void* stream);
+int hdb_launch_qcentre(const void* Q, int nq, int d, bool f64, void* Qc, float* qscale, void* stream);
 int hdb_launch_recency(const double* ts, int64_t n, double rb, double ts_max, float* out, void* stream);
 int hdb_mfma_supported(int dtype, int d, int metric);
 int hdb_mfma_tile_rows(int d);
@@ -79,6 +81,10 @@ struct hdb_index {
     int64_t bits_npad = 0;
     int W = 0;
     bool bits_valid = false;
+    // pearson per-row scale 1/(sd*d) (owned, lazy)
+    float* pscale = nullptr;
+    int64_t pscale_rows = 0;
+    bool pscale_valid = false;
     // borrowed
     const float* bias = nullptr;
     const uint8_t* mask = nullptr;
@@ -138,6 +144,7 @@ static int build_caches(hdb_index* ix, hipStream_t st) {
     HIP_TRY(hipMemsetAsync(ix->nan_flag, 0, sizeof(int), st));
     if (ix->n > 0) LAUNCH_TRY(hdb_launch_rownorm(ix->V, ix->n, ix->d, ix->dtype, ix->inv_norm, ix->sqnorm, ix->nan_flag, st));
     ix->bits_valid = false;
+    ix->pscale_valid = false;
     ix->build_stream = st;
     return HDB_OK;
 }
@@ -179,6 +186,7 @@ extern "C" void hdb_index_destroy(hdb_index* ix) {
     if (ix->sqnorm) (void)hipFree(ix->sqnorm);
     if (ix->nan_flag) (void)hipFree(ix->nan_flag);
     if (ix->bits) (void)hipFree(ix->bits);
+    if (ix->pscale) (void)hipFree(ix->pscale);
     if (ix->ws) (void)hipFree(ix->ws);
     for (hipEvent_t e : ix->ev_pool) (void)hipEventDestroy(e);
     delete ix;
@@ -261,9 +269,20 @@ static void prof_end(hdb_index* ix, hipStream_t st) {
     ix->ev_used += 2;
 }
 
-static bool metric_ok(int metric) {
-    return metric == HDB_DOT || metric == HDB_COSINE || metric == HDB_EUCLIDEAN || metric == HDB_HAMMING ||
-           metric == HDB_EUCLIDEAN_DIST;
+static bool metric_ok(int metric) { return metric >= HDB_DOT && metric <= HDB_EUCLIDEAN_DIST; }
+static bool is_bits_metric(int metric) { return metric == HDB_HAMMING || metric == HDB_JACCARD; }
+
+static int ensure_pscale(hdb_index* ix, hipStream_t st) {
+    if (ix->pscale_valid) return HDB_OK;
+    if (ix->n > ix->pscale_rows) {
+        if (ix->pscale) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(ix->pscale)); ix->pscale = nullptr; }
+        const int64_t rows = ix->n + ix->n / 4 + 64;
+        HIP_TRY(hipMalloc((void**)&ix->pscale, rows * sizeof(float)));
+        ix->pscale_rows = rows;
+    }
+    if (ix->n > 0) LAUNCH_TRY(hdb_launch_rowstats(ix->V, ix->n, ix->d, ix->dtype, ix->pscale, st));
+    ix->pscale_valid = true;
+    return HDB_OK;
 }
 
 static int ensure_bits(hdb_index* ix, hipStream_t st) {
@@ -296,7 +315,7 @@ static void base_args(const hdb_index* ix, ScanArgs& a, const void* Q, int metri
 struct QueryBufs { const float* qinv; const float* qsq; const uint32_t* qbits; const void* q16; };
 static int run_scan(hdb_index* ix, ScanArgs& a, int mode, int cq, const QueryBufs& qb, bool mfma, hipStream_t st) {
     a.qinv = qb.qinv;
-    if (a.metric == HDB_HAMMING) {
+    if (is_bits_metric(a.metric)) {
         LAUNCH_TRY(hdb_launch_hamming(&a, mode, cq, ix->bits, ix->bits_npad, ix->W, qb.qbits, st));
     } else if (mfma) {
         LAUNCH_TRY(hdb_launch_mfma_scan(&a, mode, cq, qb.q16, ix->sqnorm, qb.qsq, (int)ix->max_blocks, st));
@@ -313,18 +332,25 @@ extern "C" int hdb_scores(hdb_index* ix, const void* dev_q, int metric, float* d
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st = (hipStream_t)stream;
     const int W = (ix->d + 31) / 32;
-    int rc = ensure_ws(ix, 4096 + (size_t)W * 4 + 1024);
+    int rc = ensure_ws(ix, 8192 + (size_t)W * 4 + (size_t)ix->d * 8);
     if (rc) return rc;
     Bump b(ix->ws, ix->ws_bytes);
     float* qinv = b.take<float>(1); float* qsq = b.take<float>(1); int* qnan = b.take<int>(1);
     uint32_t* qbits = b.take<uint32_t>(W);
+    void* qc = b.take<double>(ix->d);
     LAUNCH_TRY(hdb_launch_qprep(dev_q, 1, ix->d, ix->dtype == HDB_F64, qinv, qsq, qnan, st));
-    if (metric == HDB_HAMMING) {
+    if (is_bits_metric(metric)) {
         rc = ensure_bits(ix, st); if (rc) return rc;
         LAUNCH_TRY(hdb_launch_qsign(dev_q, 1, ix->d, ix->dtype == HDB_F64, W, qbits, st));
     }
     ScanArgs a; base_args(ix, a, dev_q, metric);
+    if (metric == HDB_PEARSON) {        // cosine pipeline on the centred query with 1/(sd*d) row scales
+        rc = ensure_pscale(ix, st); if (rc) return rc;
+        LAUNCH_TRY(hdb_launch_qcentre(dev_q, 1, ix->d, ix->dtype == HDB_F64, qc, qinv, st));
+        a.Q = qc; a.metric = HDB_COSINE; a.inv_norm = ix->pscale;
+    }
     a.mask = nullptr;                   // per-metric functions score every row, no bias (reference :24-147)
+    a.raw = 1;                          // ... and return NaN where the reference does (pearson, jaccard)
     a.scores = dev_out; a.ld = ix->n;
     QueryBufs qb{qinv, qsq, qbits, nullptr};
     return run_scan(ix, a, 0, 1, qb, false, st);
@@ -353,6 +379,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     if (!dev_Q) return fail(HDB_ERR_ARG, "hdb_topk: query pointer is null");
     if (k > HDB_MAX_K && ix->n > HDB_CAND_CAP) return fail(HDB_ERR_UNSUPPORTED, "hdb_topk: k > HDB_MAX_K needs the full-sort path");
     if (metric == HDB_EUCLIDEAN_DIST || !metric_ok(metric)) return fail(HDB_ERR_UNSUPPORTED, "hdb_topk: metric not built");
+    if (metric == HDB_PEARSON && ix->d < 1) return fail(HDB_ERR_ARG, "hdb_topk: pearson needs d >= 1");
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st = (hipStream_t)stream;
     const bool f64 = ix->dtype == HDB_F64;
@@ -368,11 +395,12 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     if ((size_t)std::min<int64_t>(k, HDB_CAND_CAP) > HDB_CAND_CAP) return fail(HDB_ERR_ARG, "hdb_topk: k too large");
 
     const bool small = n <= HDB_CAND_CAP;
-    const bool is_ham = metric == HDB_HAMMING;
+    const bool is_ham = is_bits_metric(metric);
+    const bool is_pearson = metric == HDB_PEARSON;
     if (is_ham && !small) exact = true;                      // integer scores: massive ties by construction
     if (ix->force_exact && !small) exact = true;
     const bool mfma = ix->use_mfma && !is_ham && !small && !ix->mask && nq >= ix->mfma_min_q &&
-                      hdb_mfma_supported(ix->dtype, ix->d, metric);
+                      hdb_mfma_supported(ix->dtype, ix->d, is_pearson ? (int)HDB_COSINE : metric);
     const int tile_rows = mfma ? hdb_mfma_tile_rows(ix->d) : 16;
 
     // ---- plan the chunking --------------------------------------------------------------------
@@ -389,6 +417,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     need += 3 * align_up((size_t)nq * 4, 256) + 1024;                        // qinv, qsq, qnan
     need += align_up((size_t)nq * W * 4, 256);                               // qbits
     need += align_up((size_t)nq * ix->d * 2, 256);                           // fp16 queries (MFMA)
+    need += align_up((size_t)nq * ix->d * 8, 256);                           // centred queries (pearson)
     need += 2 * align_up((size_t)cq_max * 4, 256);                           // thr, cnt
     need += align_up((size_t)cq_max * 4 * HDB_RADIX_BINS * 4, 256);          // hist
     need += align_up((size_t)cq_max * 16, 256);                              // tie_info
@@ -400,6 +429,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     float* qinv = b.take<float>(nq); float* qsq = b.take<float>(nq); int* qnan = b.take<int>(nq);
     uint32_t* qbits = b.take<uint32_t>((size_t)nq * W);
     void* q16 = b.take<uint16_t>((size_t)nq * ix->d);
+    void* qc = b.take<double>((size_t)nq * ix->d);
     float* thr = b.take<float>(cq_max); uint32_t* cnt = b.take<uint32_t>(cq_max);
     uint32_t* hist = b.take<uint32_t>((size_t)cq_max * 4 * HDB_RADIX_BINS);
     uint32_t* tie_info = b.take<uint32_t>((size_t)cq_max * 4);
@@ -412,6 +442,13 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
         rc = ensure_bits(ix, st); if (rc) return rc;
         LAUNCH_TRY(hdb_launch_qsign(dev_Q, nq, ix->d, f64, W, qbits, st));
     }
+    const void* Qeff = dev_Q;
+    int metric_eff = metric;
+    if (is_pearson) {
+        rc = ensure_pscale(ix, st); if (rc) return rc;
+        LAUNCH_TRY(hdb_launch_qcentre(dev_Q, nq, ix->d, f64, qc, qinv, st));     // qinv <- 1/sd_q
+        Qeff = qc; metric_eff = HDB_COSINE;
+    }
     bool q16_ready = false;
     ix->st_sample_rows = s_rows; ix->st_sample_m = m; ix->st_chunks = 0;
     ix->st_path = small ? 0 : (exact ? 2 : 1);
@@ -420,9 +457,10 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     for (int q0 = 0; q0 < nq; q0 += cq_max) {
         const int cq = std::min(cq_max, nq - q0);
         ix->st_chunks++;
-        if (mfma && !q16_ready) { LAUNCH_TRY(hdb_launch_q_to_f16((const float*)dev_Q, nq, ix->d, q16, st)); q16_ready = true; }
+        if (mfma && !q16_ready) { LAUNCH_TRY(hdb_launch_q_to_f16((const float*)Qeff, nq, ix->d, q16, st)); q16_ready = true; }
         QueryBufs qb{qinv, qsq, qbits, q16};
-        ScanArgs a; base_args(ix, a, dev_Q, metric);
+        ScanArgs a; base_args(ix, a, Qeff, metric_eff);
+        if (is_pearson) a.inv_norm = ix->pscale;
         a.q0 = q0; a.bias = ix->bias;
         a.thr = thr; a.cnt = cnt; a.cand = cand;
         a.ntiles = (n + tile_rows - 1) / tile_rows;

@@ -39,6 +39,7 @@ struct ScanArgs {
     unsigned long long* cand;  // [nq][cap]
     uint32_t cap;
     int32_t nq;             // total number of queries behind Q
+    int32_t raw;            // 1: keep NaN scores as NaN (per-metric functions); 0: NaN -> -inf (ranking)
     int32_t dbg;            // timing-only ablation bits (results are wrong when set): 1 no LDS-DMA, 2 no MFMA, 4 no filter
 };
 

@@ -130,8 +130,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
 
     // ---- roles ----------------------------------------------------------------------------------------
     // Waves 0-3 ("A") and 4-7 ("B") are the two waves of each SIMD.  B runs its threshold epilogue one tile
-    // late (while A, at raised priority, owns the matrix pipe) so that the two waves of a SIMD do not reach
-    // MFMA phase, epilogue and barrier in lock-step.
+    // late so that the two waves of a SIMD do not reach MFMA phase, epilogue and barrier in lock-step.
     const bool grpB = w >= 4;
 
     // ---- staging geometry (per lane, fixed for the whole kernel) -----------------------------------
@@ -278,7 +277,10 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
         const bool more = i + 2 < my_tiles && !(a.dbg & 1);
         const int st_next2 = st_cur == 0 ? 2 : st_cur - 1;      // buffer of tile i+2 == the one tile i-1 used
         if (more) issue_aux(i + 2, st_next2);
-        if (more && !wave_active) {
+        // Stage the whole next-but-one tile right after the barrier (measured: 5.4-5.7 TB/s on the HBM-bound
+        // shapes vs 4.7-5.0 when the pieces are spread between the MFMAs; no difference at Q=256).  dbg 32 spreads.
+        const bool bulk = !wave_active || !(a.dbg & 32);
+        if (more && bulk) {
 #pragma unroll
             for (int j = 0; j < NG; ++j) issue_piece(i + 2, st_next2, j);
         }
@@ -325,7 +327,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
                     else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
                 }
             };
-            if (!grpB && !(a.dbg & 16)) __builtin_amdgcn_s_setprio(2);
+            if (!grpB && (a.dbg & 16)) __builtin_amdgcn_s_setprio(2);      // optional: A waves first on the matrix pipe
             if (!(a.dbg & 2)) {
                 fetch(0, abuf[0]);
                 if (KS > 1) fetch(1, abuf[1]);
@@ -337,9 +339,9 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
                     for (int rt = 0; rt < RT; ++rt) acc[rt] = Shape::mma(abuf[s % 3][rt], Bq[s], acc[rt]);
                     // LDS-DMA pieces of tile i+2 ride between the MFMAs: one every KS/NG k-steps
                     constexpr int EVERY = KS / NG;
-                    if (s % EVERY == EVERY / 2 && s / EVERY < NG) { if (more) issue_piece(i + 2, st_next2, s / EVERY); }
+                    if (s % EVERY == EVERY / 2 && s / EVERY < NG) { if (more && !bulk) issue_piece(i + 2, st_next2, s / EVERY); }
                 }
-            } else if (more) {
+            } else if (more && !bulk) {
 #pragma unroll
                 for (int j = 0; j < NG; ++j) issue_piece(i + 2, st_next2, j);
             }

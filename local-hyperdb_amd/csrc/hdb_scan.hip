@@ -44,6 +44,8 @@ __device__ __forceinline__ void hdb_emit(const ScanArgs& a, int q, int64_t row, 
     float s;
     if (a.metric == HDB_EUCLIDEAN) {
         s = (float)(Acc(1) / (Acc(1) + sqrt(sum)));                       // 1/(1+||v-q||), :49-51
+    } else if (a.metric == HDB_MANHATTAN) {
+        s = (float)(Acc(1) / (Acc(1) + sum));                             // 1/(1+sum|v-q|), :59-60
     } else if (a.metric == HDB_EUCLIDEAN_DIST) {
         s = (float)sqrt(sum);
     } else if (a.metric == HDB_COSINE) {
@@ -54,7 +56,7 @@ __device__ __forceinline__ void hdb_emit(const ScanArgs& a, int q, int64_t row, 
     if (a.bias) s += a.bias[row];                                          // recency, :186
     const bool masked = a.mask && !a.mask[row];                            // filtered-out row
     if (masked) s = -INFINITY;
-    s = hdb_canon(s);                                                      // NaN -> -inf, :174
+    if (!a.raw) s = hdb_canon(s);                                          // NaN -> -inf, :174
     if (MODE == 0) {
         a.scores[(int64_t)(q - a.q0) * a.ld + out_i] = s;
     } else {
@@ -72,7 +74,7 @@ __device__ __forceinline__ void hdb_emit(const ScanArgs& a, int q, int64_t row, 
 // NJ > 0: compile-time number of 16-chunk steps per row (d*sizeof(T) == NJ*256), fully unrolled so
 // that all 4*NJ loads of a tile are in flight together; NJ == 0: runtime loop, any nchunks.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int QT, int MODE, bool EUCLID, int NJ>
+template <typename T, int QT, int MODE, int ACC, int NJ>
 __global__ __launch_bounds__(256) void hdb_scan_kernel(ScanArgs a, int nq_end) {
     using Acc = typename Elem<T>::Acc;
     constexpr int EPC = Elem<T>::EPC;
@@ -128,9 +130,12 @@ __global__ __launch_bounds__(256) void hdb_scan_kernel(ScanArgs a, int nq_end) {
 #pragma unroll
                     for (int e = 0; e < EPC; ++e) {
                         // lanes past the end of a ragged row (live == false) contribute exactly 0
-                        if (EUCLID) {
+                        if (ACC == 1) {
                             const Acc df = live ? x[u][e] - qv[e] : Acc(0);
                             acc[u][qt] += df * df;
+                        } else if (ACC == 2) {
+                            const Acc df = live ? x[u][e] - qv[e] : Acc(0);
+                            acc[u][qt] += df < Acc(0) ? -df : df;
                         } else {
                             acc[u][qt] += (live ? x[u][e] : Acc(0)) * qv[e];
                         }
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(256) void hdb_scan_kernel(ScanArgs a, int nq_end) {
 // ------------------------------------------------------------------------------------------------
 // Generic scan: any d / alignment (element-wise loads).  Same tiling, one query per launch row.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int MODE, bool EUCLID>
+template <typename T, int MODE, int ACC>
 __global__ __launch_bounds__(256) void hdb_scan_generic_kernel(ScanArgs a, int nq_end) {
     using Acc = typename Elem<T>::Acc;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -180,7 +185,8 @@ __global__ __launch_bounds__(256) void hdb_scan_generic_kernel(ScanArgs a, int n
             for (int u = 0; u < 4; ++u) {
                 const int64_t r = min(r0 + u, a.n - 1);
                 const Acc x = (Acc)hdb_to_f(Vt[r * (int64_t)a.d + e]);
-                if (EUCLID) { const Acc df = x - qv; acc[u] += df * df; }
+                if (ACC == 1) { const Acc df = x - qv; acc[u] += df * df; }
+                else if (ACC == 2) { const Acc df = x - qv; acc[u] += df < Acc(0) ? -df : df; }
                 else acc[u] += x * qv;
             }
         }
@@ -296,7 +302,8 @@ __global__ __launch_bounds__(64) void hdb_qsign_kernel(const Acc* Q, int nq, int
 }
 
 // grid = (blocks, nq); each thread owns 4 consecutive rows.
-template <int MODE>
+// JACCARD: |v & q| / |v | q| on the same sign bits (ranking_algorithm.py:63-75), 0/0 -> NaN like numpy.
+template <int MODE, bool JACCARD>
 __global__ __launch_bounds__(256) void hdb_hamming_kernel(ScanArgs a, const uint32_t* bits, int64_t npad, int W,
                                                           const uint32_t* qbits, int nq_end) {
     __shared__ uint32_t qb[512];
@@ -305,17 +312,25 @@ __global__ __launch_bounds__(256) void hdb_hamming_kernel(ScanArgs a, const uint
     __syncthreads();
     const int64_t nquads = (a.n + 3) / 4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nquads; i += (int64_t)gridDim.x * 256) {
-        uint32_t mism[4] = {0, 0, 0, 0};
+        uint32_t mism[4] = {0, 0, 0, 0}, uni[4] = {0, 0, 0, 0};
         for (int w = 0; w < W; ++w) {
             const uint4 v = *reinterpret_cast<const uint4*>(bits + (int64_t)w * npad + 4 * i);
             const uint32_t qq = qb[w];
-            mism[0] += __popc(v.x ^ qq); mism[1] += __popc(v.y ^ qq);
-            mism[2] += __popc(v.z ^ qq); mism[3] += __popc(v.w ^ qq);
+            if (JACCARD) {
+                mism[0] += __popc(v.x & qq); mism[1] += __popc(v.y & qq); mism[2] += __popc(v.z & qq); mism[3] += __popc(v.w & qq);
+                uni[0] += __popc(v.x | qq); uni[1] += __popc(v.y | qq); uni[2] += __popc(v.z | qq); uni[3] += __popc(v.w | qq);
+            } else {
+                mism[0] += __popc(v.x ^ qq); mism[1] += __popc(v.y ^ qq);
+                mism[2] += __popc(v.z ^ qq); mism[3] += __popc(v.w ^ qq);
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int64_t row = 4 * i + u;
-            if (row < a.n && q < nq_end) hdb_emit<MODE>(a, q, row, row, (float)(a.d - (int)mism[u]));
+            if (row < a.n && q < nq_end) {
+                const float sc = JACCARD ? (float)mism[u] / (float)uni[u] : (float)(a.d - (int)mism[u]);
+                hdb_emit<MODE>(a, q, row, row, sc);
+            }
         }
     }
 }
@@ -323,7 +338,7 @@ __global__ __launch_bounds__(256) void hdb_hamming_kernel(ScanArgs a, const uint
 // ------------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------------
-template <typename T, int QT, int MODE, bool EUCLID>
+template <typename T, int QT, int MODE, int ACC>
 static void launch_vec(const ScanArgs& a, int nq_launch, int blocks, hipStream_t st) {
     using Acc = typename Elem<T>::Acc;
     const dim3 grid(blocks, (nq_launch + QT - 1) / QT);
@@ -331,32 +346,35 @@ static void launch_vec(const ScanArgs& a, int nq_launch, int blocks, hipStream_t
     const int nq_end = a.q0 + nq_launch;
     if constexpr (QT == 1) {   // fully unrolled variants only for one query: with QT=4 they spill
         const int nj = (a.nchunks % 16 == 0) ? a.nchunks / 16 : 0;
-        if (nj == 3) { hipLaunchKernelGGL((hdb_scan_kernel<T, QT, MODE, EUCLID, 3>), grid, dim3(256), lds, st, a, nq_end); return; }
-        if (nj == 6) { hipLaunchKernelGGL((hdb_scan_kernel<T, QT, MODE, EUCLID, 6>), grid, dim3(256), lds, st, a, nq_end); return; }
+        if (nj == 3) { hipLaunchKernelGGL((hdb_scan_kernel<T, QT, MODE, ACC, 3>), grid, dim3(256), lds, st, a, nq_end); return; }
+        if (nj == 6) { hipLaunchKernelGGL((hdb_scan_kernel<T, QT, MODE, ACC, 6>), grid, dim3(256), lds, st, a, nq_end); return; }
     }
-    hipLaunchKernelGGL((hdb_scan_kernel<T, QT, MODE, EUCLID, 0>), grid, dim3(256), lds, st, a, nq_end);
+    hipLaunchKernelGGL((hdb_scan_kernel<T, QT, MODE, ACC, 0>), grid, dim3(256), lds, st, a, nq_end);
 }
 
 template <typename T, int MODE>
 static void launch_scan_t(const ScanArgs& a, int nq_launch, int blocks, bool vec, hipStream_t st) {
     using Acc = typename Elem<T>::Acc;
-    const bool euclid = (a.metric == HDB_EUCLIDEAN || a.metric == HDB_EUCLIDEAN_DIST);
+    const int accm = (a.metric == HDB_EUCLIDEAN || a.metric == HDB_EUCLIDEAN_DIST) ? 1 : (a.metric == HDB_MANHATTAN ? 2 : 0);
     const size_t lds4 = (size_t)4 * a.d * sizeof(Acc);
     if (!vec) {
         const dim3 grid(blocks, nq_launch);
         const size_t lds = (size_t)a.d * sizeof(Acc);
         const int nq_end = a.q0 + nq_launch;
-        if (euclid) hipLaunchKernelGGL((hdb_scan_generic_kernel<T, MODE, true>), grid, dim3(256), lds, st, a, nq_end);
-        else hipLaunchKernelGGL((hdb_scan_generic_kernel<T, MODE, false>), grid, dim3(256), lds, st, a, nq_end);
+        if (accm == 1) hipLaunchKernelGGL((hdb_scan_generic_kernel<T, MODE, 1>), grid, dim3(256), lds, st, a, nq_end);
+        else if (accm == 2) hipLaunchKernelGGL((hdb_scan_generic_kernel<T, MODE, 2>), grid, dim3(256), lds, st, a, nq_end);
+        else hipLaunchKernelGGL((hdb_scan_generic_kernel<T, MODE, 0>), grid, dim3(256), lds, st, a, nq_end);
         return;
     }
     const bool qt4 = nq_launch >= 3 && lds4 <= 60 * 1024;
     if (qt4) {
-        if (euclid) launch_vec<T, 4, MODE, true>(a, nq_launch, blocks, st);
-        else launch_vec<T, 4, MODE, false>(a, nq_launch, blocks, st);
+        if (accm == 1) launch_vec<T, 4, MODE, 1>(a, nq_launch, blocks, st);
+        else if (accm == 2) launch_vec<T, 4, MODE, 2>(a, nq_launch, blocks, st);
+        else launch_vec<T, 4, MODE, 0>(a, nq_launch, blocks, st);
     } else {
-        if (euclid) launch_vec<T, 1, MODE, true>(a, nq_launch, blocks, st);
-        else launch_vec<T, 1, MODE, false>(a, nq_launch, blocks, st);
+        if (accm == 1) launch_vec<T, 1, MODE, 1>(a, nq_launch, blocks, st);
+        else if (accm == 2) launch_vec<T, 1, MODE, 2>(a, nq_launch, blocks, st);
+        else launch_vec<T, 1, MODE, 0>(a, nq_launch, blocks, st);
     }
 }
 
@@ -415,8 +433,11 @@ extern "C" int hdb_launch_hamming(const ScanArgs* args, int mode, int nq_launch,
     const ScanArgs& a = *args;
     const dim3 grid(hdb_grid_for((a.n + 3) / 4, 256, 2048), nq_launch);
     const int nq_end = a.q0 + nq_launch;
-    if (mode == 0) hipLaunchKernelGGL(hdb_hamming_kernel<0>, grid, dim3(256), 0, st, a, bits, npad, W, qbits, nq_end);
-    else hipLaunchKernelGGL(hdb_hamming_kernel<1>, grid, dim3(256), 0, st, a, bits, npad, W, qbits, nq_end);
+    const bool jac = a.metric == HDB_JACCARD;
+    if (mode == 0) { if (jac) hipLaunchKernelGGL((hdb_hamming_kernel<0, true>), grid, dim3(256), 0, st, a, bits, npad, W, qbits, nq_end);
+                     else hipLaunchKernelGGL((hdb_hamming_kernel<0, false>), grid, dim3(256), 0, st, a, bits, npad, W, qbits, nq_end); }
+    else { if (jac) hipLaunchKernelGGL((hdb_hamming_kernel<1, true>), grid, dim3(256), 0, st, a, bits, npad, W, qbits, nq_end);
+           else hipLaunchKernelGGL((hdb_hamming_kernel<1, false>), grid, dim3(256), 0, st, a, bits, npad, W, qbits, nq_end); }
     return (int)hipGetLastError();
 }
 
@@ -429,5 +450,74 @@ __global__ __launch_bounds__(256) void hdb_recency_kernel(const double* ts, int6
 }
 extern "C" int hdb_launch_recency(const double* ts, int64_t n, double rb, double ts_max, float* out, void* stream) {
     hipLaunchKernelGGL(hdb_recency_kernel, dim3(hdb_grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, ts, n, rb, ts_max, out);
+    return (int)hipGetLastError();
+}
+
+// Pearson (ranking_algorithm.py:77-113): r = sum((v-mv)(q-mq)) / (sd_v * sd_q * d).  Because sum(q-mq) = 0 the
+// numerator is the plain dot product of v with the CENTRED query, so pearson runs on the cosine pipeline with
+// two substitutions: per-row scale 1/(sd_v*d) instead of 1/||v|| (NaN for a constant row, like the reference's
+// NaN rule :107-111) and per-query scale 1/sd_q (NaN for a constant query).  Row statistics are two-pass
+// (mean, then centred squares) to avoid the cancellation of E[v^2]-E[v]^2.
+template <typename T>
+__global__ __launch_bounds__(256) void hdb_rowstats_kernel(const T* V, int64_t n, int d, float* pscale) {
+    using Acc = typename Elem<T>::Acc;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, l16 = lane & 15;
+    const int64_t ntiles = (n + 15) / 16;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += (int64_t)gridDim.x * 4) {
+        const int64_t r0 = t * 16 + 4 * g;
+        Acc acc[4] = {Acc(0), Acc(0), Acc(0), Acc(0)};
+        for (int e = l16; e < d; e += 16)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] += (Acc)hdb_to_f(V[min(r0 + u, n - 1) * (int64_t)d + e]);
+        const Acc mean = hdb_rows4_sum(acc[0], acc[1], acc[2], acc[3], l16) / Acc(d);   // mean of the OWNED row
+        const int uo = hdb_owned_row(l16);
+        // every lane needs the mean of each of its 4 rows: broadcast from the owning lanes of the group
+        Acc mu[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int src = (lane & 48) + ((u & 1) * 8 + (u >> 1) * 4);     // lane of this group that owns row u
+            mu[u] = __shfl(mean, src, 64);
+        }
+        Acc var[4] = {Acc(0), Acc(0), Acc(0), Acc(0)};
+        for (int e = l16; e < d; e += 16)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const Acc df = (Acc)hdb_to_f(V[min(r0 + u, n - 1) * (int64_t)d + e]) - mu[u]; var[u] += df * df; }
+        const Acc ss = hdb_rows4_sum(var[0], var[1], var[2], var[3], l16);
+        const int64_t row = r0 + uo;
+        if ((l16 & 3) == 0 && row < n) {
+            const Acc sd = sqrt(ss / Acc(d));
+            pscale[row] = (sd == Acc(0)) ? NAN : (float)(Acc(1) / (sd * Acc(d)));
+        }
+    }
+}
+
+template <typename Acc>
+__global__ __launch_bounds__(64) void hdb_qcentre_kernel(const Acc* Q, int nq, int d, Acc* Qc, float* qscale) {
+    const int q = blockIdx.x;
+    Acc s = Acc(0);
+    for (int e = threadIdx.x; e < d; e += 64) s += Q[(int64_t)q * d + e];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const Acc mean = s / Acc(d);
+    Acc v = Acc(0);
+    for (int e = threadIdx.x; e < d; e += 64) { const Acc c = Q[(int64_t)q * d + e] - mean; Qc[(int64_t)q * d + e] = c; v += c * c; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (threadIdx.x == 0) { const Acc sd = sqrt(v / Acc(d)); qscale[q] = (sd == Acc(0)) ? NAN : (float)(Acc(1) / sd); }
+}
+
+extern "C" int hdb_launch_rowstats(const void* V, int64_t n, int d, int dtype, float* pscale, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = hdb_grid_for((n + 15) / 16, 4, 2048);
+    if (dtype == HDB_F16) hipLaunchKernelGGL(hdb_rowstats_kernel<__half>, dim3(blocks), dim3(256), 0, st, (const __half*)V, n, d, pscale);
+    else if (dtype == HDB_F32) hipLaunchKernelGGL(hdb_rowstats_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)V, n, d, pscale);
+    else hipLaunchKernelGGL(hdb_rowstats_kernel<double>, dim3(blocks), dim3(256), 0, st, (const double*)V, n, d, pscale);
+    return (int)hipGetLastError();
+}
+extern "C" int hdb_launch_qcentre(const void* Q, int nq, int d, bool f64, void* Qc, float* qscale, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (f64) hipLaunchKernelGGL(hdb_qcentre_kernel<double>, dim3(nq), dim3(64), 0, st, (const double*)Q, nq, d, (double*)Qc, qscale);
+    else hipLaunchKernelGGL(hdb_qcentre_kernel<float>, dim3(nq), dim3(64), 0, st, (const float*)Q, nq, d, (float*)Qc, qscale);
     return (int)hipGetLastError();
 }

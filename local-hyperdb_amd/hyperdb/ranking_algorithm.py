@@ -16,8 +16,8 @@ reference's return types (int64 indices, float64 scores, ValueError on NaN / unk
 
 Additive surface (the reference has no batched call): :func:`rank_batch`.
 
-There is NO CPU fallback: without the HIP library importing this module fails, and metrics that
-have no kernel yet raise ``NotImplementedError`` instead of silently computing on the host.
+There is NO CPU fallback: without the HIP library importing this module fails, and without a GPU every
+call raises ``HyperDBNativeError`` instead of silently computing on the host.
 """
 from __future__ import annotations
 
@@ -33,7 +33,7 @@ __all__ = [
     "hyperDB_ranking_algorithm_sort", "rank_batch", "register_vectors", "ResidentVectors",
 ]
 
-_GPU_METRICS = ("dot_product", "cosine_similarity", "euclidean_metric", "hamming_distance")
+_GPU_METRICS = tuple(METRIC_IDS)      # all seven metrics of the reference's dispatch table have kernels
 _ALL_METRICS = tuple(METRIC_IDS)
 
 
@@ -170,25 +170,24 @@ def hamming_distance(vectors, query_vector):
     return out
 
 
-def _not_built(name):
-    raise NotImplementedError(
-        f"{name} has no HIP kernel yet (SURVEY.md section 8f, 'next' row); "
-        "this build has no CPU fallback by design.")
-
-
 def manhattan_distance(vectors, query_vector):
-    """reference :54-61 - not on the north-star path; kernel pending."""
-    _not_built("manhattan_distance")
+    """1/(1+sum|v-q|) per row (reference :54-61)."""
+    return _scores(vectors, query_vector, METRIC_IDS["manhattan_distance"])
 
 
 def jaccard_similarity(vectors, query_vector):
-    """reference :63-75 - not on the north-star path; kernel pending."""
-    _not_built("jaccard_similarity")
+    """|v AND q| / |v OR q| on the x>0 bits, NaN where both are empty (reference :63-75); float64 like numpy's
+    true division.  A numpy ``query_vector`` is binarised in place, as in the reference."""
+    out = _scores(vectors, query_vector, METRIC_IDS["jaccard_similarity"], out_dtype=np.float64)
+    if isinstance(query_vector, np.ndarray) and query_vector.flags.writeable:
+        check_and_binarize_vectors(query_vector)
+    return out
 
 
 def pearson_correlation(vectors, query_vector):
-    """reference :77-113 - not on the north-star path; kernel pending."""
-    _not_built("pearson_correlation")
+    """Pearson r per row, NaN when the row or the query is constant (reference :77-113); float64."""
+    return _scores(vectors, np.asarray(_query_host(query_vector)).reshape(-1), METRIC_IDS["pearson_correlation"],
+                   out_dtype=np.float64)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -197,8 +196,7 @@ def pearson_correlation(vectors, query_vector):
 def _validate_metric(metric):
     if metric not in _ALL_METRICS:
         raise ValueError(f"Unknown metric: {metric}")            # reference :166
-    if metric not in _GPU_METRICS:
-        _not_built(metric)
+
 
 
 def _apply_recency(ix, timestamps, recency_bias):
@@ -244,7 +242,8 @@ def hyperDB_ranking_algorithm_sort(vectors, query_vector, top_k=5, metric='cosin
         finally:
             if had_bias:
                 ix.set_bias(None)
-        if metric == "hamming_distance" and isinstance(query_vector, np.ndarray) and query_vector.flags.writeable:
+        if metric in ("hamming_distance", "jaccard_similarity") and isinstance(query_vector, np.ndarray) \
+                and query_vector.flags.writeable:
             check_and_binarize_vectors(query_vector)
         return idx[0].astype(np.int64), sc[0].astype(np.float64)
     finally:

@@ -271,7 +271,7 @@ def check_topk(got_idx, got_scores, vectors, query_vector, metric, top_k, *, bia
         return exact
     assert got_idx.min() >= 0 and got_idx.max() < n, "index out of range"
     assert np.unique(got_idx).shape[0] == k, "duplicate indices in top-k"
-    assert np.all(np.diff(got_scores) <= 0), "scores not sorted descending"
+    assert np.all(got_scores[1:] <= got_scores[:-1]), "scores not sorted descending"   # (-inf, -inf) pairs allowed
     ref_at = exact[got_idx]
     finite = np.isfinite(ref_at)
     band = tol * np.maximum(1.0, np.abs(ref_at))

@@ -105,5 +105,6 @@ def test_host_helpers_match_reference_semantics():
     assert np.array_equal(ranking.check_and_binarize_vectors(a), orc.binarize_inplace(b)) and np.array_equal(a, b)
     with pytest.raises(ValueError):
         ranking._validate_metric("unknown_metric")
-    with pytest.raises(NotImplementedError):
-        ranking._validate_metric("pearson_correlation")
+    for m in ("dot_product", "cosine_similarity", "euclidean_metric", "manhattan_distance", "jaccard_similarity",
+              "pearson_correlation", "hamming_distance"):
+        ranking._validate_metric(m)          # every metric of the reference's dispatch table is accepted

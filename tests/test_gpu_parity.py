@@ -17,7 +17,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-GPU_METRICS = ("dot_product", "cosine_similarity", "euclidean_metric", "hamming_distance")
+GPU_METRICS = ("dot_product", "cosine_similarity", "euclidean_metric", "hamming_distance",
+               "manhattan_distance", "jaccard_similarity", "pearson_correlation")
+INTEGER_METRICS = ("hamming_distance",)
 
 
 @pytest.fixture(scope="module")
@@ -42,6 +44,8 @@ def _load(golden_dir, name):
 def _tol(dtype, metric):
     if metric == "hamming_distance":
         return 0.0
+    if metric == "jaccard_similarity":
+        return 1e-6                      # ratio of two integers <= d, computed in float32 on the device
     return 1e-3 if np.dtype(dtype) == np.float16 else 1e-5
 
 
@@ -71,9 +75,23 @@ class TestReferenceKnownAnswersOnGpu:
         r = ranking.hamming_distance(np.array([[1, 1], [0, 1], [1, 0]]), np.array([1, 1]))
         assert np.array_equal(r, [2, 1, 1])
 
+    def test_manhattan(self, ranking):
+        r = ranking.manhattan_distance(np.array([[1, 0], [0, 1]]), np.array([1, 0]))
+        assert np.allclose(r, [1.0, 1 / 3])
+
+    def test_jaccard(self, ranking):
+        assert np.array_equal(ranking.jaccard_similarity(np.array([[1, 1], [1, 0], [0, 0]]), np.array([1, 1])), [1.0, 0.5, 0.0])
+        assert np.array_equal(ranking.jaccard_similarity(np.array([[2, 2], [2, 0], [0, 0]]), np.array([1, 1])), [1.0, 0.5, 0.0])
+
+    def test_pearson(self, ranking):
+        r = ranking.pearson_correlation(np.array([[1, 1], [0, 1], [1, 0]]), np.array([1, 1]))
+        assert np.isnan(r[0]) and r[1] != 0.0 and r[2] != 0.0
+        assert np.all(np.isnan(ranking.pearson_correlation(np.array([[1, 1], [0, 0], [1, 1]]), np.array([1, 1]))))
+
     @pytest.mark.parametrize("metric, rb, expected", [
         ("cosine_similarity", 0, [0, 2, 1]), ("cosine_similarity", 1, [2, 0, 1]),
-        ("euclidean_metric", 0, [0, 2, 1]), ("hamming_distance", 0, [0, 2, 1]), ("dot_product", 0, [0, 2, 1])])
+        ("euclidean_metric", 0, [0, 2, 1]), ("hamming_distance", 0, [0, 2, 1]), ("dot_product", 0, [0, 2, 1]),
+        ("manhattan_distance", 0, [0, 2, 1]), ("jaccard_similarity", 0, [0, 2, 1]), ("pearson_correlation", 0, [0, 1, 2])])
     def test_sort(self, ranking, metric, rb, expected):
         V = np.array([[1, 0], [0, 1], [0.5, 0.5]])
         idx, _ = ranking.hyperDB_ranking_algorithm_sort(
@@ -130,15 +148,16 @@ def test_sweep_golden_topk(ranking, orc, golden_dir):
         if bias is not None:
             tol = max(tol, 1e-5)        # the recency term is a float32 on the device (integer scores stop being integers)
         orc.check_topk(idx, sc, V, q, c["metric"], c["top_k"], bias=bias, tol=tol)
-        if c["metric"] == "hamming_distance" and bias is None:
-            # bit-exact score multiset; tie order canonical on our side, arbitrary in the reference
-            assert np.array_equal(np.sort(sc), np.sort(ref_sc)), c["name"]
+        if c["metric"] in ("hamming_distance", "jaccard_similarity") and bias is None:
+            # massive ties: bit-exact (hamming) / float32-exact (jaccard = ratio of two small integers) score
+            # multiset; tie order canonical on our side, arbitrary in the reference
+            assert np.allclose(np.sort(sc), np.sort(ref_sc), rtol=1e-6, atol=0, equal_nan=True), c["name"]
         else:
             assert orc.same_result_modulo_ties(idx, sc, ref_idx, ref_sc, tol), c["name"]
         n_checked += 1
     for h in handles.values():
         h.close()
-    assert n_checked == 4 * 8 * 2 * 4 + 4 * 8 * 2       # metrics x mats x queries x k  + recency cases
+    assert n_checked == 7 * 8 * 2 * 4 + 7 * 8 * 2       # metrics x mats x queries x k  + recency cases
 
 
 def test_sweep_golden_full_vectors(ranking, golden_dir):
@@ -159,7 +178,9 @@ def test_sweep_golden_full_vectors(ranking, golden_dir):
         else:
             tol = _tol(V.dtype, c["metric"])
             g, w = got.astype(np.float64), want.astype(np.float64)
-            assert np.all(np.abs(g - w) <= 2 * tol * np.maximum(1, np.abs(w))), (key, np.abs(g - w).max())
+            assert np.array_equal(np.isnan(g), np.isnan(w)), key           # pearson / jaccard NaN rules
+            ok = ~np.isnan(w)
+            assert np.all(np.abs(g[ok] - w[ok]) <= 2 * tol * np.maximum(1, np.abs(w[ok]))), (key, np.abs(g[ok] - w[ok]).max())
 
 
 def test_edge_golden(ranking, orc, golden_dir, capsys):
@@ -179,9 +200,9 @@ def test_edge_golden(ranking, orc, golden_dir, capsys):
         assert np.asarray(idx).shape == ref_idx.shape, name
         assert np.asarray(sc).shape == ref_sc.shape, name          # includes the (1,1) single-row quirk
         assert printed == c["printed"], name
-        if c["metric"] == "hamming_distance":
+        if c["metric"] in ("hamming_distance", "jaccard_similarity"):
             assert np.array_equal(q, z[name + ".q_after"]), name    # in-place binarisation of the query
-            assert np.array_equal(np.sort(np.asarray(sc).ravel()), np.sort(ref_sc.ravel())), name
+            assert np.allclose(np.sort(np.asarray(sc).ravel()), np.sort(ref_sc.ravel()), rtol=1e-6, atol=0), name
             continue
         tol = _tol(V.dtype, c["metric"])
         if len(ref_idx) == 0:
@@ -216,8 +237,8 @@ def test_oracle_parity_medium(ranking, orc, dtype, n, d):
                 oi, osc = orc.rank(V, q.copy(), top_k=100, metric=metric)
                 tol = _tol(dtype, metric)
                 orc.check_topk(idx, sc, V, q, metric, 100, tol=tol)
-                if metric == "hamming_distance":
-                    assert np.array_equal(sc, np.sort(osc)[::-1]), (metric, qi)
+                if metric in ("hamming_distance", "jaccard_similarity"):
+                    assert np.allclose(sc, np.sort(osc)[::-1], rtol=1e-6, atol=0), (metric, qi)
                 else:
                     assert orc.same_result_modulo_ties(idx, sc, oi, osc, tol), (metric, qi)
         assert h.index.stat("path") in (1, 2)

@@ -1,0 +1,22 @@
+import sys
+sys.path.insert(0, 'local-hyperdb_amd'); sys.path.insert(0, '.')
+import torch
+from hyperdb._native import GpuIndex, METRIC_IDS
+import bench
+dev = torch.device('cuda', 0)
+for (n, d, q, metric) in ((10_000_000, 768, 64, 'euclidean_metric'), (10_000_000, 384, 256, 'dot_product'), (10_000_000, 384, 64, 'cosine_similarity')):
+    V, lo, hi = bench.make_shard(n, d, torch.float16, 0, 1, dev)
+    ix = GpuIndex(V)
+    Q = bench.make_queries(q, d, torch.float16, dev)
+    mid = METRIC_IDS[metric]
+    for flags in (0, 32, 16, 48):
+        ix.set_option('debug_flags', flags)
+        for _ in range(2): ix.topk_device(Q, 100, mid)
+        ix.set_option('profile', 1)
+        torch.cuda.synchronize()
+        for _ in range(5): ix.topk_device(Q, 100, mid)
+        torch.cuda.synchronize()
+        ns, l = ix.stat('scan_time_ns'), ix.stat('scan_launches')
+        ix.set_option('profile', 0)
+        print(f"d={d} q={q} {metric} flags={flags} (bulk={(flags>>5)&1} noprio={(flags>>4)&1}): kernel {ns/l/1e3:.1f} us  -> {n*d*2/(ns/l):.2f} GB/s", flush=True)
+    ix.close(); del V; torch.cuda.empty_cache()
