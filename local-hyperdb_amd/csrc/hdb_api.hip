@@ -92,7 +92,7 @@ struct hdb_index {
     char* ws = nullptr;
     size_t ws_bytes = 0;
     // options
-    int64_t max_blocks = 2048;
+    int64_t max_blocks = 0;           // 0 = automatic (row scan: 2-4 workgroups per CU, see hdb_launch_scan)
     int64_t force_exact = 0;
     int64_t sample_target = 0;        // 0 = automatic
     int64_t mfma_min_q = 8;
@@ -216,7 +216,7 @@ extern "C" int hdb_index_set_row_mask(hdb_index* ix, const uint8_t* dev_mask) {
 
 extern "C" int hdb_set_option(hdb_index* ix, const char* name, int64_t value) {
     if (!ix || !name) return fail(HDB_ERR_ARG, "hdb_set_option: null argument");
-    if (!strcmp(name, "max_blocks")) ix->max_blocks = std::max<int64_t>(1, value);
+    if (!strcmp(name, "max_blocks")) ix->max_blocks = std::max<int64_t>(0, value);
     else if (!strcmp(name, "force_exact")) ix->force_exact = value;
     else if (!strcmp(name, "sample_target")) ix->sample_target = value;
     else if (!strcmp(name, "mfma_min_q")) ix->mfma_min_q = value;

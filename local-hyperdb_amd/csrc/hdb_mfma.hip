@@ -157,7 +157,9 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
             const int rr = r <= (int)last ? r : (int)last;
             off = (unsigned int)(g_off[j] + (rr - r) * (D * 2));
         }
-        __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(tile_base + off), HDB_LDS_PTR(sdst + (w + 8 * j) * 1024), 16, 0, 0);
+        // aux = 2: non-temporal (V is read once per pass by exactly one CU); dbg 128 falls back to the default policy
+        if (a.dbg & 128) __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(tile_base + off), HDB_LDS_PTR(sdst + (w + 8 * j) * 1024), 16, 0, 0);
+        else __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(tile_base + off), HDB_LDS_PTR(sdst + (w + 8 * j) * 1024), 16, 0, 2);
     };
     auto issue_aux = [&](int64_t i, int st) {
         if ((AUX0 || HAS_BIAS) && grpB) {

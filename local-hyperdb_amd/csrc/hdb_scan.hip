@@ -113,8 +113,14 @@ __global__ __launch_bounds__(256) void hdb_scan_kernel(ScanArgs a, int nq_end) {
             const bool live = NJ > 0 ? true : (c < a.nchunks);
             const int cc = live ? c : a.nchunks - 1;
             uint4 raw[4];
+            // non-temporal loads: V is streamed exactly once per query, keeping it out of the caches' LRU
+            // measured +10 % (5.9 -> 6.5 TB/s at N=10M d=384 fp16, 2 workgroups per CU)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const uint4*>(p[u] + (int64_t)cc * 16);
+            for (int u = 0; u < 4; ++u) {
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p[u] + (int64_t)cc * 16));
+                raw[u] = make_uint4(v.x, v.y, v.z, v.w);
+            }
             Acc x[4][EPC];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -387,7 +393,9 @@ extern "C" int hdb_launch_scan(const ScanArgs* args, int dtype, int mode, int nq
     a.nchunks = a.row_bytes / 16;
     const bool vec = (a.row_bytes % 16 == 0) && ((reinterpret_cast<uintptr_t>(a.V) & 15) == 0) &&
                      ((size_t)a.d * (elem == 8 ? 8 : 4) <= 60 * 1024);
-    const int blocks = hdb_grid_for(a.ntiles, 4, max_blocks);
+    // grid: measured optimum (non-temporal row stream) is 2 workgroups per CU for 768-byte rows, 4 for longer ones
+    const int auto_blocks = (a.nchunks == 48) ? 512 : 1024;
+    const int blocks = hdb_grid_for(a.ntiles, 4, max_blocks > 0 ? max_blocks : auto_blocks);
     if (dtype == HDB_F16) { if (mode == 0) launch_scan_t<__half, 0>(a, nq_launch, blocks, vec, st); else launch_scan_t<__half, 1>(a, nq_launch, blocks, vec, st); }
     else if (dtype == HDB_F32) { if (mode == 0) launch_scan_t<float, 0>(a, nq_launch, blocks, vec, st); else launch_scan_t<float, 1>(a, nq_launch, blocks, vec, st); }
     else { if (mode == 0) launch_scan_t<double, 0>(a, nq_launch, blocks, vec, st); else launch_scan_t<double, 1>(a, nq_launch, blocks, vec, st); }

@@ -9,7 +9,7 @@ for (n, d, q, metric) in ((10_000_000, 768, 64, 'euclidean_metric'), (10_000_000
     ix = GpuIndex(V)
     Q = bench.make_queries(q, d, torch.float16, dev)
     mid = METRIC_IDS[metric]
-    for flags in (0, 32, 16, 48):
+    for flags in (0, 128, 0, 128):
         ix.set_option('debug_flags', flags)
         for _ in range(2): ix.topk_device(Q, 100, mid)
         ix.set_option('profile', 1)
@@ -18,5 +18,5 @@ for (n, d, q, metric) in ((10_000_000, 768, 64, 'euclidean_metric'), (10_000_000
         torch.cuda.synchronize()
         ns, l = ix.stat('scan_time_ns'), ix.stat('scan_launches')
         ix.set_option('profile', 0)
-        print(f"d={d} q={q} {metric} flags={flags} (bulk={(flags>>5)&1} noprio={(flags>>4)&1}): kernel {ns/l/1e3:.1f} us  -> {n*d*2/(ns/l):.2f} GB/s", flush=True)
+        print(f"d={d} q={q} {metric} flags={flags} (default_policy={(flags>>7)&1}): kernel {ns/l/1e3:.1f} us  -> {n*d*2/(ns/l):.2f} GB/s", flush=True)
     ix.close(); del V; torch.cuda.empty_cache()
