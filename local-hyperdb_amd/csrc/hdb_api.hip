@@ -482,7 +482,6 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
                 LAUNCH_TRY(hdb_launch_thr(hist, cq, 4, m, (uint32_t)s_rows, thr, cnt, st));
             }
             // 3) the pass over all of V
-            if (ix->debug_flags & 8) a.scores = sbuf;      // diagnostic stamps land in the (now idle) sample buffer
             prof_begin(ix, st);
             rc = run_scan(ix, a, 1, cq, qb, mfma, st); if (rc) return rc;
             prof_end(ix, st);

@@ -44,16 +44,6 @@ template <int N> __device__ __forceinline__ void hdb_wait_vmcnt() {
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else static_assert(N < 0, "add this vmcnt immediate");
 }
-__device__ __forceinline__ unsigned long long hdb_stamp() {
-    unsigned long long t;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
-    return t;
-}
-__device__ __forceinline__ unsigned long long hdb_stamp_real() {
-    unsigned long long t;
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
-    return t;
-}
 __device__ __forceinline__ void hdb_lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -141,40 +131,41 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
         const int r = slot / CPR, cpos = slot - r * CPR;
         g_off[j] = r * (D * 2) + (cpos ^ (r & 15)) * 16;   // source byte for this LDS slot (XOR swizzle of the chunk)
     }
-    const char* Vb = reinterpret_cast<const char*>(a.V);
-    const int64_t my_tiles = (a.ntiles > blockIdx.x) ? (a.ntiles - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    // loop-invariant scalars, read once (keeps kernel-argument loads out of the tile loop)
+    const char* const Vb = reinterpret_cast<const char*>(a.V);
+    const int64_t n_rows = a.n;
+    const int64_t ntiles = a.ntiles;
+    const int64_t rows_per_tile_step = a.tile_stride * R;       // rows between consecutive tile indices
+    const int64_t gstep = gridDim.x;
+    const int64_t my_tiles = (ntiles > blockIdx.x) ? (ntiles - blockIdx.x + gstep - 1) / gstep : 0;
 
-    // one LDS-DMA piece (1 KiB) of tile i into stage st
-    auto issue_piece = [&](int64_t i, int st, int j) {
-        const int64_t t = blockIdx.x + i * gridDim.x;
-        const int64_t row0 = t * a.tile_stride * R;
-        const int64_t last = a.n - 1 - row0;          // >= 0
+    // Stage tile number t (global tile index) into ring slot st: NG LDS-DMA pieces of 1 KiB per wave,
+    // non-temporal (V is read once per pass by exactly one CU: +2-3 % on the HBM-bound shapes), plus the
+    // per-row aux values (B waves only).  Only the last tile of the matrix can be ragged.
+    auto issue = [&](int64_t t, int st) {
+        const int64_t row0 = t * rows_per_tile_step;
+        const int64_t last = n_rows - 1 - row0;          // >= 0
         char* sdst = smem + st * STAGE;
         const char* tile_base = Vb + row0 * (int64_t)(D * 2);          // wave-uniform
-        unsigned int off = (unsigned int)g_off[j];
-        if (last < R - 1) {                                             // ragged last tile: clamp rows to the last one
-            const int r = g_off[j] / (D * 2);
-            const int rr = r <= (int)last ? r : (int)last;
-            off = (unsigned int)(g_off[j] + (rr - r) * (D * 2));
+        if (last >= R - 1) {
+#pragma unroll
+            for (int j = 0; j < NG; ++j)
+                __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(tile_base + (unsigned int)g_off[j]),
+                                                 HDB_LDS_PTR(sdst + (w + 8 * j) * 1024), 16, 0, 2);
+        } else {                                                        // clamp rows past the end to the last row
+#pragma unroll
+            for (int j = 0; j < NG; ++j) {
+                const int r = g_off[j] / (D * 2);
+                const int rr = r <= (int)last ? r : (int)last;
+                const unsigned int off = (unsigned int)(g_off[j] + (rr - r) * (D * 2));
+                __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(tile_base + off), HDB_LDS_PTR(sdst + (w + 8 * j) * 1024), 16, 0, 2);
+            }
         }
-        // aux = 2: non-temporal (V is read once per pass by exactly one CU); dbg 128 falls back to the default policy
-        if (a.dbg & 128) __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(tile_base + off), HDB_LDS_PTR(sdst + (w + 8 * j) * 1024), 16, 0, 0);
-        else __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(tile_base + off), HDB_LDS_PTR(sdst + (w + 8 * j) * 1024), 16, 0, 2);
-    };
-    auto issue_aux = [&](int64_t i, int st) {
         if ((AUX0 || HAS_BIAS) && grpB) {
-            const int64_t t = blockIdx.x + i * gridDim.x;
-            const int64_t row0 = t * a.tile_stride * R;
-            const int64_t last = a.n - 1 - row0;
             const int64_t rr = lane <= last ? lane : last;
             if (AUX0) __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(aux0g + row0 + rr), HDB_LDS_PTR(auxbuf + (st * 2 + 0) * 64), 4, 0, 0);
             if (HAS_BIAS) __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(a.bias + row0 + rr), HDB_LDS_PTR(auxbuf + (st * 2 + 1) * 64), 4, 0, 0);
         }
-    };
-    auto issue = [&](int64_t i, int st) {
-#pragma unroll
-        for (int j = 0; j < NG; ++j) issue_piece(i, st, j);
-        issue_aux(i, st);
     };
 
     auto flush = [&]() {
@@ -191,8 +182,9 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
         hdb_lds_barrier();
     };
 
-    if (my_tiles > 0) issue(0, 0);
-    if (my_tiles > 1) issue(1, 1);
+    int64_t t_cur = blockIdx.x;                      // global index of the tile being multiplied
+    if (my_tiles > 0) issue(t_cur, 0);
+    if (my_tiles > 1) issue(t_cur + gstep, 1);
 
     const unsigned int smem_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(smem);
     const unsigned int ctl_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(ctl);
@@ -236,7 +228,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float x = tv[rt][4 * g + j];
-                            if (x >= thr_cmp && rowg + j < a.n) {
+                            if (x >= thr_cmp && rowg + j < n_rows) {
                                 const float sc = hdb_canon((METRIC == 1 && !HAS_BIAS) ? x * qinv_l : x);
                                 // LDS ops in inline asm: hipcc would otherwise drain every in-flight LDS-DMA
                                 // (s_waitcnt vmcnt(0)) before touching LDS it cannot prove disjoint from the ring.
@@ -261,39 +253,20 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
     Acc acc[RT];
     int64_t row0_prev = 0;
     int st_cur = 0;
-    // diagnostic stamps (dbg & 8, timing study only): block 0, lane 0 of waves 0 and 4, first 64 tiles,
-    // 8 stamps per tile, written to the (otherwise unused in filter mode) scores pointer
-    const bool stamping = MODE == 1 && (a.dbg & 8) && blockIdx.x == 0 && lane == 0 && (w == 0 || w == 4);
-    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(a.scores) + (w == 4 ? 64 * 8 : 0);
-#define HDB_STAMP(k) do { if (stamping && i < 64) stamps[i * 8 + (k)] = hdb_stamp(); } while (0)
-    if (stamping) { stamps[2 * 64 * 8 + (w == 4 ? 2 : 0)] = hdb_stamp(); stamps[2 * 64 * 8 + (w == 4 ? 3 : 1)] = hdb_stamp_real(); }
-    for (int64_t i = 0; i < my_tiles; ++i) {
-        HDB_STAMP(0);
+    for (int64_t i = 0; i < my_tiles; ++i, t_cur += gstep) {
         if (i + 1 >= my_tiles) hdb_wait_vmcnt<0>();
         else if (grpB) hdb_wait_vmcnt<NLOADB>();
         else hdb_wait_vmcnt<NLOADA>();
         if (MODE == 1 && tid == 0) ctl[1 + (i & 1)] = (ctl[0] >= HDB_MFMA_CB / 2) ? 1u : 0u;
-        HDB_STAMP(1);
         hdb_lds_barrier();                                   // tile i is in LDS; everyone is done with tile i-1
-        HDB_STAMP(2);
-        const bool more = i + 2 < my_tiles && !(a.dbg & 1);
-        const int st_next2 = st_cur == 0 ? 2 : st_cur - 1;      // buffer of tile i+2 == the one tile i-1 used
-        if (more) issue_aux(i + 2, st_next2);
-        // Stage the whole next-but-one tile right after the barrier (measured: 5.4-5.7 TB/s on the HBM-bound
-        // shapes vs 4.7-5.0 when the pieces are spread between the MFMAs; no difference at Q=256).  dbg 32 spreads.
-        const bool bulk = !wave_active || !(a.dbg & 32);
-        if (more && bulk) {
-#pragma unroll
-            for (int j = 0; j < NG; ++j) issue_piece(i + 2, st_next2, j);
-        }
+        // Stage the whole next-but-one tile right after the barrier, into the buffer tile i-1 used (measured:
+        // 5.4-5.7 TB/s on the HBM-bound shapes vs 4.7-5.0 with the pieces spread between the MFMAs).
+        if (i + 2 < my_tiles) issue(t_cur + 2 * gstep, st_cur == 0 ? 2 : st_cur - 1);
         if (MODE == 1 && ctl[1 + (i & 1)]) flush();
-        HDB_STAMP(3);
 
         if (wave_active) {
-            const int64_t t = blockIdx.x + i * gridDim.x;
-            const int64_t row0 = t * a.tile_stride * R;
-            if (MODE == 1 && grpB && i > 0 && !(a.dbg & 4)) filter(acc, row0_prev);        // deferred epilogue of tile i-1
-            HDB_STAMP(4);
+            const int64_t row0 = t_cur * rows_per_tile_step;
+            if (MODE == 1 && grpB && i > 0) filter(acc, row0_prev);        // deferred epilogue of tile i-1
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -329,26 +302,15 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
                     else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
                 }
             };
-            if (!grpB && (a.dbg & 16)) __builtin_amdgcn_s_setprio(2);      // optional: A waves first on the matrix pipe
-            if (!(a.dbg & 2)) {
-                fetch(0, abuf[0]);
-                if (KS > 1) fetch(1, abuf[1]);
+            fetch(0, abuf[0]);
+            if (KS > 1) fetch(1, abuf[1]);
 #pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    if (s + 2 < KS) fetch(s + 2, abuf[(s + 2) % 3]);
-                    wait_frag(s + 2 < KS ? 2 : (s + 1 < KS ? 1 : 0), abuf[s % 3]);
+            for (int s = 0; s < KS; ++s) {
+                if (s + 2 < KS) fetch(s + 2, abuf[(s + 2) % 3]);
+                wait_frag(s + 2 < KS ? 2 : (s + 1 < KS ? 1 : 0), abuf[s % 3]);
 #pragma unroll
-                    for (int rt = 0; rt < RT; ++rt) acc[rt] = Shape::mma(abuf[s % 3][rt], Bq[s], acc[rt]);
-                    // LDS-DMA pieces of tile i+2 ride between the MFMAs: one every KS/NG k-steps
-                    constexpr int EVERY = KS / NG;
-                    if (s % EVERY == EVERY / 2 && s / EVERY < NG) { if (more && !bulk) issue_piece(i + 2, st_next2, s / EVERY); }
-                }
-            } else if (more && !bulk) {
-#pragma unroll
-                for (int j = 0; j < NG; ++j) issue_piece(i + 2, st_next2, j);
+                for (int rt = 0; rt < RT; ++rt) acc[rt] = Shape::mma(abuf[s % 3][rt], Bq[s], acc[rt]);
             }
-            if (!grpB) __builtin_amdgcn_s_setprio(0);
-            HDB_STAMP(5);
 
             // ---- epilogue, first half: turn the dot products into the values that are stored (MODE 0) or
             // compared (MODE 1), in place.  Filter mode compares the score itself, except cosine without
@@ -394,25 +356,22 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
 #pragma unroll
                         for (int j = 0; j < 4; ++j) sj[j] = hdb_canon(acc[rt][4 * g + j]);
                         if (q_ok) {
-                            float* dst = a.scores + (int64_t)ql * a.ld + (t * R + rl0);
-                            if (rowg + 3 < a.n) *reinterpret_cast<float4*>(dst) = make_float4(sj[0], sj[1], sj[2], sj[3]);
+                            float* dst = a.scores + (int64_t)ql * a.ld + (t_cur * R + rl0);
+                            if (rowg + 3 < n_rows) *reinterpret_cast<float4*>(dst) = make_float4(sj[0], sj[1], sj[2], sj[3]);
                             else {
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) if (rowg + j < a.n) dst[j] = sj[j];
+                                for (int j = 0; j < 4; ++j) if (rowg + j < n_rows) dst[j] = sj[j];
                             }
                         }
                     }
                 }
             } else {
-                if (!grpB) { if (!(a.dbg & 4)) filter(acc, row0); }
+                if (!grpB) filter(acc, row0);
                 else row0_prev = row0;
             }
-            HDB_STAMP(6);
         }
         st_cur = st_cur == 2 ? 0 : st_cur + 1;
     }
-    if (stamping) { stamps[2 * 64 * 8 + (w == 4 ? 6 : 4)] = hdb_stamp(); stamps[2 * 64 * 8 + (w == 4 ? 7 : 5)] = hdb_stamp_real(); }
-#undef HDB_STAMP
     if (MODE == 1) {
         if (wave_active && grpB && my_tiles > 0) filter(acc, row0_prev);
         flush();
