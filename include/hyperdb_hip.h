@@ -132,7 +132,9 @@ int64_t hdb_packed_bytes(int32_t nq, int32_t k);
 int hdb_merge_topk_packed(const void* dev_gathered, int32_t parts, int32_t nq, int32_t k, int64_t* dev_idx,
                           float* dev_score, int32_t* dev_status, int device, void* stream);
 
-/* Largest k served by hdb_topk / hdb_topk_exact / hdb_merge_topk without the full-sort path. */
+/* Largest k served by the selection kernels.  hdb_topk / hdb_topk_exact accept any k: above HDB_MAX_K (on a
+ * matrix of more than 8192 rows) they materialise the scores of each query and radix-sort them (cold path,
+ * "top_k > N returns all rows sorted", ranking_algorithm.py:195-200).  hdb_merge_topk* need parts*k <= 8192. */
 #define HDB_MAX_K 2048
 
 /* Tuning knobs / introspection (bench and tests): name -> value, returns HDB_ERR_ARG if unknown. */

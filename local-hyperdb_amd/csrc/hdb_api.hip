@@ -45,6 +45,9 @@ int hdb_mfma_tile_rows(int d);
 int hdb_launch_mfma_scan(const ScanArgs* args, int mode, int nq_launch, const void* q16, const float* sqnorm,
                          const float* qsq, int max_blocks, void* stream);
 int hdb_launch_q_to_f16(const float* Q, int nq, int d, void* q16, void* stream);
+int hdb_sort_temp_bytes(int64_t n, size_t* bytes);
+int hdb_launch_full_sort(const float* scores, int64_t n, int64_t k, int64_t row_base, uint32_t* work, void* temp, size_t temp_bytes,
+                         int64_t* idx_out, float* score_out, void* stream);
 int hdb_launch_rescore_euclid(unsigned long long* cand, const uint32_t* cnt, uint32_t cap, int nq_launch, const void* V, int d,
                               const float* Q, int q0, const float* bias, void* stream);
 }
@@ -377,7 +380,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     if (nq < 0 || k < 0) return fail(HDB_ERR_ARG, "hdb_topk: nq and k must be >= 0");
     if (nq == 0 || k == 0) return HDB_OK;
     if (!dev_Q) return fail(HDB_ERR_ARG, "hdb_topk: query pointer is null");
-    if (k > HDB_MAX_K && ix->n > HDB_CAND_CAP) return fail(HDB_ERR_UNSUPPORTED, "hdb_topk: k > HDB_MAX_K needs the full-sort path");
+    const bool full_sort = k > HDB_MAX_K && ix->n > HDB_CAND_CAP;
     if (metric == HDB_EUCLIDEAN_DIST || !metric_ok(metric)) return fail(HDB_ERR_UNSUPPORTED, "hdb_topk: metric not built");
     if (metric == HDB_PEARSON && ix->d < 1) return fail(HDB_ERR_ARG, "hdb_topk: pearson needs d >= 1");
     HIP_TRY(hipSetDevice(ix->device));
@@ -448,6 +451,39 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
         rc = ensure_pscale(ix, st); if (rc) return rc;
         LAUNCH_TRY(hdb_launch_qcentre(dev_Q, nq, ix->d, f64, qc, qinv, st));     // qinv <- 1/sd_q
         Qeff = qc; metric_eff = HDB_COSINE;
+    }
+    if (full_sort) {
+        // cold path for huge k: one query at a time, all scores -> stable radix sort (hdb_sort.hip)
+        size_t tb = 0;
+        LAUNCH_TRY(hdb_sort_temp_bytes(n, &tb));
+        const size_t extra = align_up((size_t)n * 4, 256) + align_up((size_t)n * 16, 256) + align_up(tb, 256) + 4096;
+        // the workspace was sized before this branch was known: grow it now (all pointers above are re-derived)
+        const size_t base_need = need;
+        rc = ensure_ws(ix, base_need + extra); if (rc) return rc;
+        Bump b2(ix->ws, ix->ws_bytes);
+        float* qinv2 = b2.take<float>(nq); float* qsq2 = b2.take<float>(nq); int* qnan2 = b2.take<int>(nq);
+        uint32_t* qbits2 = b2.take<uint32_t>((size_t)nq * W);
+        (void)b2.take<uint16_t>((size_t)nq * ix->d);
+        void* qc2 = b2.take<double>((size_t)nq * ix->d);
+        float* sc1 = b2.take<float>((size_t)ld_n);
+        uint32_t* work = b2.take<uint32_t>((size_t)n * 4);
+        void* temp = b2.take<char>(tb);
+        LAUNCH_TRY(hdb_launch_qprep(dev_Q, nq, ix->d, f64, qinv2, qsq2, qnan2, st));
+        if (is_ham) LAUNCH_TRY(hdb_launch_qsign(dev_Q, nq, ix->d, f64, W, qbits2, st));
+        const void* Q2 = dev_Q;
+        if (is_pearson) { LAUNCH_TRY(hdb_launch_qcentre(dev_Q, nq, ix->d, f64, qc2, qinv2, st)); Q2 = qc2; }
+        ix->st_path = 3; ix->st_mfma = 0; ix->st_chunks = nq;
+        for (int q0 = 0; q0 < nq; ++q0) {
+            QueryBufs qb{qinv2, qsq2, qbits2, nullptr};
+            ScanArgs s2; base_args(ix, s2, Q2, metric_eff);
+            if (is_pearson) s2.inv_norm = ix->pscale;
+            s2.q0 = q0; s2.bias = ix->bias; s2.scores = sc1; s2.ld = ld_n;
+            rc = run_scan(ix, s2, 0, 1, qb, false, st); if (rc) return rc;
+            LAUNCH_TRY(hdb_launch_full_sort(sc1, n, k, ix->row_base, work, temp, tb, dev_idx + (int64_t)q0 * k,
+                                            dev_score + (int64_t)q0 * k, st));
+        }
+        if (dev_status) HIP_TRY(hipMemsetAsync(dev_status, 0, (size_t)nq * sizeof(int32_t), st));
+        return HDB_OK;
     }
     bool q16_ready = false;
     ix->st_sample_rows = s_rows; ix->st_sample_m = m; ix->st_chunks = 0;

@@ -544,3 +544,28 @@ def test_mfma_shapes_and_euclidean(orc, d, nq, metric, bias):
             assert mi_h[1][0] == 123
     finally:
         ix.close()
+
+
+@pytest.mark.parametrize("metric,k", [("cosine_similarity", 5000), ("hamming_distance", 3000), ("dot_product", 60_000)])
+def test_large_k_full_sort_path(ranking, orc, metric, k):
+    """k above HDB_MAX_K on a matrix larger than the candidate list: all-scores + stable radix sort."""
+    rng = np.random.default_rng(k)
+    n, d = 50_000, 64
+    V = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal(d).astype(np.float32)
+    h = ranking.register_vectors(V)
+    try:
+        idx, sc = ranking.hyperDB_ranking_algorithm_sort(h, q.copy(), top_k=k, metric=metric)
+        assert h.index.stat("path") == 3
+        kk = min(k, n)
+        assert idx.shape == (kk,) and sc.shape == (kk,)
+        ex = orc.exact_scores(V, q, metric)
+        ci, cs = orc.canonical(idx, sc)
+        assert np.array_equal(ci, idx), "rows must come out in (score desc, index asc) order"
+        tol = 0.0 if metric == "hamming_distance" else 1e-5
+        orc.check_topk(idx, sc, V, q, metric, k, tol=tol, exact=ex)
+        if metric == "hamming_distance":
+            want = np.lexsort((np.arange(n), -ex))[:kk]
+            assert np.array_equal(idx, want)
+    finally:
+        h.close()
