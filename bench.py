@@ -124,7 +124,7 @@ def extra_leg(name, device):
         g = torch.Generator(device=device).manual_seed(99)
         ts = 1.7e9 + torch.rand(n, generator=g, device=device, dtype=torch.float64) * 30 * 86400.0
         ix.set_recency(ts, 0.5)
-    Q = make_queries(q * 4, d, dt, device)
+    Q = make_queries(q * 4, d, dt, device).to(torch.float32)
     mid = METRIC_IDS[metric]
     for i in range(3):
         ix.topk(Q[:q], 100, mid)
@@ -178,7 +178,8 @@ def main():
     local = GpuIndex(V, device=device, row_base=lo)
     sharded = ShardedIndex(local, n_total=args.n, group=(dist.group.WORLD if dist else None),
                            force_exchange=os.environ.get("HDB_FORCE_DIST") == "1")
-    Q = make_queries(max(args.steps + args.warmup, 1), args.d, tdtype, device)
+    # queries: fp16/fp32 values as the config says, staged in the C ABI's query type (float32: exact for fp16)
+    Q = make_queries(max(args.steps + args.warmup, 1), args.d, tdtype, device).to(torch.float32)
     mid = METRIC_IDS[args.metric]
     torch.cuda.synchronize()
 
@@ -216,7 +217,7 @@ def main():
     batched = None
     if args.batch_q > 0:
         bq = args.batch_q
-        QB = make_queries(bq, args.d, tdtype, device)
+        QB = make_queries(bq, args.d, tdtype, device).to(torch.float32)
         bmid = METRIC_IDS["dot_product"]
         for _ in range(2):
             sharded.query(QB, args.k, bmid)

@@ -29,6 +29,7 @@ int hdb_launch_hamming(const ScanArgs* args, int mode, int nq_launch, const uint
 int hdb_launch_hist(const float* scores, int64_t n, int64_t ld, int nq, uint32_t* hist, int pass, uint32_t k, void* stream);
 int hdb_launch_thr(const uint32_t* hist, int nq, int npass, uint32_t m, uint32_t sample_n, float* thr, uint32_t* cnt, void* stream);
 int hdb_launch_fill_thr(float* thr, uint32_t* cnt, int nq, float v, void* stream);
+void hdb_set_finalize_threads(int t);
 int hdb_launch_sample_thr(const float* scores, int64_t n, int64_t ld, int nq, uint32_t m, float* thr, uint32_t* cnt, void* stream);
 int hdb_launch_collect(const float* scores, int64_t n, int64_t ld, int nq, const uint32_t* hist, uint32_t k, uint32_t* cnt,
                        unsigned long long* cand, uint32_t cap, uint32_t* tie_info, void* stream);
@@ -226,6 +227,7 @@ extern "C" int hdb_set_option(hdb_index* ix, const char* name, int64_t value) {
     else if (!strcmp(name, "use_mfma")) ix->use_mfma = value;
     else if (!strcmp(name, "exact_bytes")) ix->exact_bytes = std::max<int64_t>(1 << 20, value);
     else if (!strcmp(name, "debug_flags")) ix->debug_flags = value;
+    else if (!strcmp(name, "finalize_threads")) hdb_set_finalize_threads((int)value);
     else if (!strcmp(name, "profile")) { ix->profile = value; ix->ev_used = 0; }
     else return fail(HDB_ERR_ARG, std::string("hdb_set_option: unknown option ") + name);
     return HDB_OK;
@@ -402,6 +404,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     const bool is_pearson = metric == HDB_PEARSON;
     if (is_ham && !small) exact = true;                      // integer scores: massive ties by construction
     if (ix->force_exact && !small) exact = true;
+    if (!small && (int64_t)kk * 32 > n) exact = true;        // k is a large share of the rows: a sampled threshold cannot help
     const bool mfma = ix->use_mfma && !is_ham && !small && !ix->mask && nq >= ix->mfma_min_q &&
                       hdb_mfma_supported(ix->dtype, ix->d, is_pearson ? (int)HDB_COSINE : metric);
     const int tile_rows = mfma ? hdb_mfma_tile_rows(ix->d) : 16;

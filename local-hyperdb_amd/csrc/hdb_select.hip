@@ -298,7 +298,7 @@ __device__ uint32_t hdb_preselect(unsigned long long* buf, uint32_t nc, uint32_t
     __syncthreads();
     // suffix scan from the top bin: thread t owns bins NB-1-2t, NB-2-2t (1024 threads) -- generic stride
     const uint32_t per = (NB + nth - 1) / nth;
-    uint32_t loc[4]; uint32_t tot = 0;
+    uint32_t loc[8]; uint32_t tot = 0;              // per <= 8 (blockDim >= 256)
     for (uint32_t j = 0; j < per; ++j) { const uint32_t b = tid * per + j; loc[j] = b < NB ? hist[NB - 1 - b] : 0; tot += loc[j]; }
     uint32_t incl = tot;
 #pragma unroll
@@ -443,6 +443,8 @@ extern "C" int hdb_launch_collect(const float* scores, int64_t n, int64_t ld, in
     hipLaunchKernelGGL(hdb_ties_seq_kernel, dim3(nq), dim3(1024), 0, (hipStream_t)stream, scores, n, ld, cnt, cand, cap, tie_info);
     return (int)hipGetLastError();
 }
+static int g_finalize_threads = 1024;
+extern "C" void hdb_set_finalize_threads(int t) { if (t == 256 || t == 512 || t == 1024) g_finalize_threads = t; }
 extern "C" int hdb_launch_finalize(const unsigned long long* cand, const uint32_t* cnt, uint32_t cap, int nq, uint32_t k,
                                    uint32_t kk, int64_t row_base, int64_t* idx_out, float* score_out, int32_t* status,
                                    const int* qnan, void* stream) {
@@ -453,7 +455,7 @@ extern "C" int hdb_launch_finalize(const unsigned long long* cand, const uint32_
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL(hdb_finalize_kernel, dim3(nq), dim3(1024), lds, (hipStream_t)stream, cand, cnt, cap, k, kk,
+    hipLaunchKernelGGL(hdb_finalize_kernel, dim3(nq), dim3(g_finalize_threads), lds, (hipStream_t)stream, cand, cnt, cap, k, kk,
                        row_base, idx_out, score_out, status, qnan);
     return (int)hipGetLastError();
 }

@@ -569,3 +569,94 @@ def test_large_k_full_sort_path(ranking, orc, metric, k):
             assert np.array_equal(idx, want)
     finally:
         h.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# 7. boundaries of the pipeline: candidate-cap edge, forced threshold failures, lifecycle
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [8191, 8192, 8193, 8208])
+def test_candidate_cap_boundary(ranking, orc, n):
+    rng = np.random.default_rng(n)
+    V = rng.standard_normal((n, 32)).astype(np.float32)
+    q = rng.standard_normal(32).astype(np.float32)
+    h = ranking.register_vectors(V)
+    try:
+        for k in (1, 100, 2048):
+            idx, sc = ranking.hyperDB_ranking_algorithm_sort(h, q, top_k=k, metric="dot_product")
+            oi, osc = orc.rank(V, q, top_k=k, metric="dot_product")
+            assert list(idx) == list(oi) and np.allclose(sc, osc, rtol=1e-5, atol=1e-5), (n, k)
+        # k=2048 of ~8200 rows goes straight to the exact path (k > n/32); the smaller k use the sampled threshold
+        assert h.index.stat("path") == (0 if n <= 8192 else 2)
+        ranking.hyperDB_ranking_algorithm_sort(h, q, top_k=100, metric="dot_product")
+        assert h.index.stat("path") == (0 if n <= 8192 else 1)
+    finally:
+        h.close()
+
+
+@pytest.mark.parametrize("target", [16, 200_000])
+def test_forced_threshold_failure_falls_back_to_exact(orc, target):
+    """sample_target=16 makes the threshold far too high (fewer than k survivors -> UNDERFLOW),
+    200000 far too low (more than 8192 survivors -> OVERFLOW); both must end in the exact answer."""
+    import torch
+    from hyperdb._native import GpuIndex, METRIC_IDS
+    rng = np.random.default_rng(target)
+    n, d, k = 300_000, 64, 100
+    V = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((3, d)).astype(np.float32)
+    ix = GpuIndex(V)
+    try:
+        ix.set_option("sample_target", target)
+        mid = METRIC_IDS["cosine_similarity"]
+        _, _, st = ix.topk_device(Q, k, mid)
+        assert int((st != 0).sum().item()) == 3, "the test did not provoke the failure it is about"
+        assert set(st.cpu().tolist()) == ({1} if target == 16 else {2})
+        idx, sc = ix.topk(Q, k, mid)                       # host entry: re-runs the failed queries exactly
+        for qi in range(3):
+            oi, osc = orc.rank(V, Q[qi], top_k=k, metric="cosine_similarity")
+            assert list(idx[qi]) == list(oi) and np.allclose(sc[qi], osc, atol=1e-5)
+    finally:
+        ix.close()
+
+
+def test_index_update_lifecycle(orc):
+    """hdb_index_update: grow / shrink the resident matrix; caches (norms, NaN flag, sign bits) follow."""
+    from hyperdb._native import GpuIndex, METRIC_IDS
+    rng = np.random.default_rng(9)
+    V = rng.standard_normal((20_000, 48)).astype(np.float32)
+    q = rng.standard_normal(48).astype(np.float32)
+    ix = GpuIndex(V[:9000])
+    try:
+        for metric in ("cosine_similarity", "hamming_distance", "pearson_correlation"):
+            i1, s1 = ix.topk(q.reshape(1, -1), 10, METRIC_IDS[metric])
+            o1, os1 = orc.rank(V[:9000], q.copy(), top_k=10, metric=metric)
+            assert np.allclose(np.sort(s1[0]), np.sort(os1), atol=1e-5)
+        ix.update(V)                                       # grown to 20000 rows
+        assert ix.n == 20_000 and not ix.has_nan
+        for metric in ("cosine_similarity", "hamming_distance", "pearson_correlation"):
+            i2, s2 = ix.topk(q.reshape(1, -1), 10, METRIC_IDS[metric])
+            o2, os2 = orc.rank(V, q.copy(), top_k=10, metric=metric)
+            assert np.allclose(np.sort(s2[0]), np.sort(os2), atol=1e-5)
+            if metric == "cosine_similarity":
+                assert list(i2[0]) == list(o2)
+        Vn = V[:100].copy(); Vn[37, 5] = np.nan
+        ix.update(Vn)
+        assert ix.n == 100 and ix.has_nan
+    finally:
+        ix.close()
+
+
+def test_fp64_and_query_dtype_promotion(ranking, orc):
+    rng = np.random.default_rng(64)
+    V = rng.standard_normal((12_000, 40))                  # float64 matrix, float64 accumulate on the device
+    q = rng.standard_normal(40)
+    for metric in ("dot_product", "euclidean_metric", "manhattan_distance"):
+        idx, sc = ranking.hyperDB_ranking_algorithm_sort(V, q, top_k=25, metric=metric)
+        oi, osc = orc.rank(V, q, top_k=25, metric=metric)
+        assert list(idx) == list(oi) and np.allclose(sc, osc, rtol=1e-6, atol=1e-6)
+    d = ranking.euclidean_metric(V[:50], q, get_similarity_score=False)
+    assert np.allclose(d, orc.score_euclidean(V[:50], q, get_similarity_score=False), rtol=1e-6)
+    # integer matrix / list inputs are accepted like numpy would (promoted to float64)
+    Vi = rng.integers(-3, 4, size=(200, 6))
+    idx, sc = ranking.hyperDB_ranking_algorithm_sort(Vi.tolist(), [1, 0, 2, 0, 0, 1], top_k=5, metric="dot_product")
+    oi, osc = orc.rank(Vi, np.array([1, 0, 2, 0, 0, 1]), top_k=5, metric="dot_product")
+    assert np.allclose(sc, osc) and set(sc) == set(osc)
