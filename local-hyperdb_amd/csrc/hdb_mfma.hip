@@ -122,6 +122,11 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
     // Waves 0-3 ("A") and 4-7 ("B") are the two waves of each SIMD.  B runs its threshold epilogue one tile
     // late so that the two waves of a SIMD do not reach MFMA phase, epilogue and barrier in lock-step.
     const bool grpB = w >= 4;
+    // "heavy": all eight waves multiply (more than 4*MF queries in this pass), the matrix pipe is the bottleneck.
+    // Then A stages its half of tile i+2 right after the barrier while B already multiplies, and B stages its
+    // half after its MFMA phase while A finishes -- the two waves of a SIMD never issue LDS-DMA (~90 cycles of
+    // blocked issue per 1 KiB piece) at the same time.  Otherwise (HBM-bound) everyone stages right away.
+    const bool heavy = (nq_end - (a.q0 + (int)blockIdx.y * (8 * MF))) > 4 * MF;
 
     // ---- staging geometry (per lane, fixed for the whole kernel) -----------------------------------
     int g_off[NG];
@@ -250,6 +255,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
         }
     };
 
+    const int64_t chk_mask = ntiles >= 65536 ? 15 : 0;
     Acc acc[RT];
     int64_t row0_prev = 0;
     int st_cur = 0;
@@ -257,12 +263,18 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
         if (i + 1 >= my_tiles) hdb_wait_vmcnt<0>();
         else if (grpB) hdb_wait_vmcnt<NLOADB>();
         else hdb_wait_vmcnt<NLOADA>();
-        if (MODE == 1 && tid == 0) ctl[1 + (i & 1)] = (ctl[0] >= HDB_MFMA_CB / 2) ? 1u : 0u;
+        // the LDS candidate list is checked for a flush every 16 tiles on large matrices (a few hits per tile,
+        // 1024 slots), every tile on small ones (hits per tile ~ T*Q/ntiles): the check costs two LDS round trips
+        // on every wave's critical path
+        const bool chk = MODE == 1 && (i & chk_mask) == chk_mask;
+        if (chk && tid == 0) ctl[1] = (ctl[0] >= HDB_MFMA_CB / 2) ? 1u : 0u;
         hdb_lds_barrier();                                   // tile i is in LDS; everyone is done with tile i-1
         // Stage the whole next-but-one tile right after the barrier, into the buffer tile i-1 used (measured:
         // 5.4-5.7 TB/s on the HBM-bound shapes vs 4.7-5.0 with the pieces spread between the MFMAs).
-        if (i + 2 < my_tiles) issue(t_cur + 2 * gstep, st_cur == 0 ? 2 : st_cur - 1);
-        if (MODE == 1 && ctl[1 + (i & 1)]) flush();
+        const bool more = i + 2 < my_tiles;
+        const int st_next2 = st_cur == 0 ? 2 : st_cur - 1;
+        if (more && !(heavy && grpB)) issue(t_cur + 2 * gstep, st_next2);
+        if (chk && ctl[1]) flush();
 
         if (wave_active) {
             const int64_t row0 = t_cur * rows_per_tile_step;
@@ -278,7 +290,8 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
             // lgkmcnt(n*RT) = "all but the n*RT newest LDS ops are back" = the oldest pending step's fragments;
             // stray scalar loads can only make that wait longer, never shorter.
             const unsigned int sb_addr = smem_addr + (unsigned int)(st_cur * STAGE) + rd_base;
-            half8 abuf[3][RT];
+            constexpr int PF = 3;                              // k-steps of LDS prefetch (PF+1 fragment sets)
+            half8 abuf[PF + 1][RT];
             auto fetch = [&](int s, half8 (&dst)[RT]) {
                 const unsigned int ad = sb_addr + ((unsigned int)(16 * CPS * s) ^ hx);
                 asm volatile("ds_read_b128 %0, %1" : "=v"(dst[0]) : "v"(ad));
@@ -286,30 +299,30 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
                 if constexpr (RT > 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[2]) : "v"(ad), "i"(2 * MF * CPR * 16));
                 if constexpr (RT > 3) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[3]) : "v"(ad), "i"(3 * MF * CPR * 16));
             };
-            auto wait_frag = [&](int pending_steps, half8 (&f)[RT]) {     // fragments of the oldest step are back
+            // wait until at most `pend` k-steps of fragment reads are outstanding: lgkmcnt(pend*RT)
+            auto wait_frag = [&](int pend, half8 (&f)[RT]) {
                 static_assert(RT == 1 || RT == 2 || RT == 4, "RT");
-                if constexpr (RT == 1) {
-                    if (pending_steps == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(f[0]));
-                    else if (pending_steps == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(f[0]));
-                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]));
-                } else if constexpr (RT == 2) {
-                    if (pending_steps == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f[0]), "+v"(f[1]));
-                    else if (pending_steps == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(f[0]), "+v"(f[1]));
-                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]));
-                } else {
-                    if (pending_steps == 2) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
-                    else if (pending_steps == 1) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
-                    else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
-                }
+#define HDB_WAITF(N)                                                                                               \
+                do {                                                                                               \
+                    if constexpr (RT == 1) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(f[0]));                  \
+                    else if constexpr (RT == 2) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(f[0]), "+v"(f[1])); \
+                    else asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3])); \
+                } while (0)
+                const int cnt = pend * RT;
+                if (cnt >= 12) HDB_WAITF(12); else if (cnt == 8) HDB_WAITF(8); else if (cnt == 6) HDB_WAITF(6);
+                else if (cnt == 4) HDB_WAITF(4); else if (cnt == 3) HDB_WAITF(3); else if (cnt == 2) HDB_WAITF(2);
+                else if (cnt == 1) HDB_WAITF(1); else HDB_WAITF(0);
+#undef HDB_WAITF
             };
-            fetch(0, abuf[0]);
-            if (KS > 1) fetch(1, abuf[1]);
+#pragma unroll
+            for (int s = 0; s < PF && s < KS; ++s) fetch(s, abuf[s % (PF + 1)]);
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
-                if (s + 2 < KS) fetch(s + 2, abuf[(s + 2) % 3]);
-                wait_frag(s + 2 < KS ? 2 : (s + 1 < KS ? 1 : 0), abuf[s % 3]);
+                if (s + PF < KS) fetch(s + PF, abuf[(s + PF) % (PF + 1)]);
+                const int pend = (KS - 1 - s) < PF ? (KS - 1 - s) : PF;       // steps still in flight behind step s
+                wait_frag(pend, abuf[s % (PF + 1)]);
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) acc[rt] = Shape::mma(abuf[s % 3][rt], Bq[s], acc[rt]);
+                for (int rt = 0; rt < RT; ++rt) acc[rt] = Shape::mma(abuf[s % (PF + 1)][rt], Bq[s], acc[rt]);
             }
 
             // ---- epilogue, first half: turn the dot products into the values that are stored (MODE 0) or
@@ -370,6 +383,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
                 else row0_prev = row0;
             }
         }
+        if (more && heavy && grpB) issue(t_cur + 2 * gstep, st_next2);      // B's half of the staging, after its MFMA phase
         st_cur = st_cur == 2 ? 0 : st_cur + 1;
     }
     if (MODE == 1) {

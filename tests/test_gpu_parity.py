@@ -660,3 +660,24 @@ def test_fp64_and_query_dtype_promotion(ranking, orc):
     idx, sc = ranking.hyperDB_ranking_algorithm_sort(Vi.tolist(), [1, 0, 2, 0, 0, 1], top_k=5, metric="dot_product")
     oi, osc = orc.rank(Vi, np.array([1, 0, 2, 0, 0, 1]), top_k=5, metric="dot_product")
     assert np.allclose(sc, osc) and set(sc) == set(osc)
+
+
+def test_full_size_q256_mfma_equals_single_query_scan(big_fp16):
+    """Config 3 at full size: the 256-query MFMA pass against the single-query row scan, query by query."""
+    import torch
+    from hyperdb._native import METRIC_IDS
+    import bench
+    ix, V, _ = big_fp16
+    Q = bench.make_queries(256, 384, torch.float16, V.device)
+    mid = METRIC_IDS["dot_product"]
+    bi, bs, st = ix.topk_device(Q, 100, mid)
+    assert ix.stat("mfma") == 1 and int(st.abs().sum().item()) == 0
+    ix.set_option("use_mfma", 0)
+    try:
+        for qi in (0, 100, 255):
+            si, ss, _ = ix.topk_device(Q[qi:qi + 1], 100, mid)
+            assert ix.stat("mfma") == 0
+            assert torch.equal(si[0], bi[qi]), qi
+            assert torch.allclose(ss[0], bs[qi], rtol=2e-6, atol=2e-5)
+    finally:
+        ix.set_option("use_mfma", 1)
