@@ -43,6 +43,15 @@ struct ScanArgs {
     int32_t dbg;            // timing-only ablation bits (results are wrong when set): 1 no LDS-DMA, 2 no MFMA, 4 no filter
 };
 
+// ---- strided row sample -------------------------------------------------------------------------
+// Sample tile t of a strided sample sits at tile index t*stride + jitter(t), jitter in [0, stride): a fixed
+// pseudo-random offset inside each stride window, so that a matrix with periodic structure (rows inserted
+// round-robin by class, ...) cannot alias with the sampling period.  stride == 1 (dense scan) gives jitter 0.
+__device__ __forceinline__ int64_t hdb_tile_index(int64_t t, int64_t stride) {
+    const uint32_t h = (uint32_t)t * 2654435761u;
+    return t * stride + (int64_t)((h >> 8) % (uint32_t)stride);
+}
+
 // ---- orderable float keys -----------------------------------------------------------------
 __device__ __forceinline__ uint32_t hdb_f2key(float f) {
     uint32_t u = __float_as_uint(f);

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
     const char* const Vb = reinterpret_cast<const char*>(a.V);
     const int64_t n_rows = a.n;
     const int64_t ntiles = a.ntiles;
-    const int64_t rows_per_tile_step = a.tile_stride * R;       // rows between consecutive tile indices
+    const int64_t tstride = a.tile_stride;                      // 1 = dense pass, > 1 = strided row sample
     const int64_t gstep = gridDim.x;
     const int64_t my_tiles = (ntiles > blockIdx.x) ? (ntiles - blockIdx.x + gstep - 1) / gstep : 0;
 
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
     // non-temporal (V is read once per pass by exactly one CU: +2-3 % on the HBM-bound shapes), plus the
     // per-row aux values (B waves only).  Only the last tile of the matrix can be ragged.
     auto issue = [&](int64_t t, int st) {
-        const int64_t row0 = t * rows_per_tile_step;
+        const int64_t row0 = hdb_tile_index(t, tstride) * R;
         const int64_t last = n_rows - 1 - row0;          // >= 0
         char* sdst = smem + st * STAGE;
         const char* tile_base = Vb + row0 * (int64_t)(D * 2);          // wave-uniform
@@ -245,7 +245,10 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
                                     asm volatile("ds_write_b64 %0, %1\n\tds_write_b16 %2, %3"
                                                  :: "v"(cb_addr + pos * 8u), "v"(ent), "v"(cbq_addr + pos * 2u), "v"((unsigned int)ql) : "memory");
                                 } else {
-                                    atomicAdd(&a.cnt[ql], a.cap + 1u);   // LDS list overflowed: force the exact-path fallback
+                                    // LDS list full (dense hits on a small matrix): append straight to the global list.
+                                    // The returning atomic makes hipcc drain this wave's LDS-DMA here -- rare and only slow.
+                                    const unsigned int gpos = atomicAdd(&a.cnt[ql], 1u);
+                                    if (gpos < a.cap) a.cand[(int64_t)ql * a.cap + gpos] = hdb_pack(sc, (uint32_t)(rowg + j));
                                 }
                             }
                         }
@@ -255,7 +258,8 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
         }
     };
 
-    const int64_t chk_mask = ntiles >= 65536 ? 15 : 0;
+    const int chk_shift = ntiles >= 65536 ? 4 : 0;
+    const int64_t chk_mask = (1 << chk_shift) - 1;
     Acc acc[RT];
     int64_t row0_prev = 0;
     int st_cur = 0;
@@ -266,18 +270,22 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
         // the LDS candidate list is checked for a flush every 16 tiles on large matrices (a few hits per tile,
         // 1024 slots), every tile on small ones (hits per tile ~ T*Q/ntiles): the check costs two LDS round trips
         // on every wave's critical path
+        // The decision word alternates between ctl[1] and ctl[2] from one check to the next: waves are at most one
+        // barrier apart, so wave 0 cannot overwrite a decision that a slower wave has not read yet (a torn decision
+        // would send only part of the workgroup into flush()'s barriers).
         const bool chk = MODE == 1 && (i & chk_mask) == chk_mask;
-        if (chk && tid == 0) ctl[1] = (ctl[0] >= HDB_MFMA_CB / 2) ? 1u : 0u;
+        const int chk_slot = 1 + (int)((i >> chk_shift) & 1);
+        if (chk && tid == 0) ctl[chk_slot] = (ctl[0] >= HDB_MFMA_CB / 4) ? 1u : 0u;
         hdb_lds_barrier();                                   // tile i is in LDS; everyone is done with tile i-1
         // Stage the whole next-but-one tile right after the barrier, into the buffer tile i-1 used (measured:
         // 5.4-5.7 TB/s on the HBM-bound shapes vs 4.7-5.0 with the pieces spread between the MFMAs).
         const bool more = i + 2 < my_tiles;
         const int st_next2 = st_cur == 0 ? 2 : st_cur - 1;
         if (more && !(heavy && grpB)) issue(t_cur + 2 * gstep, st_next2);
-        if (chk && ctl[1]) flush();
+        if (chk && ctl[chk_slot]) flush();
 
         if (wave_active) {
-            const int64_t row0 = t_cur * rows_per_tile_step;
+            const int64_t row0 = hdb_tile_index(t_cur, tstride) * R;
             if (MODE == 1 && grpB && i > 0) filter(acc, row0_prev);        // deferred epilogue of tile i-1
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt)

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void hdb_scan_kernel(ScanArgs a, int nq_end) {
     const char* Vb = reinterpret_cast<const char*>(a.V);
 
     for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < a.ntiles; t += (int64_t)gridDim.x * 4) {
-        const int64_t r0 = t * a.tile_stride * 16 + 4 * g;
+        const int64_t r0 = hdb_tile_index(t, a.tile_stride) * 16 + 4 * g;
         const char* p[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void hdb_scan_generic_kernel(ScanArgs a, int n
     const int g = lane >> 4, l16 = lane & 15;
     const T* Vt = reinterpret_cast<const T*>(a.V);
     for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < a.ntiles; t += (int64_t)gridDim.x * 4) {
-        const int64_t r0 = t * a.tile_stride * 16 + 4 * g;
+        const int64_t r0 = hdb_tile_index(t, a.tile_stride) * 16 + 4 * g;
         Acc acc[4] = {Acc(0), Acc(0), Acc(0), Acc(0)};
         for (int e = l16; e < a.d; e += 16) {
             const Acc qv = qs[e];

@@ -681,3 +681,30 @@ def test_full_size_q256_mfma_equals_single_query_scan(big_fp16):
             assert torch.allclose(ss[0], bs[qi], rtol=2e-6, atol=2e-5)
     finally:
         ix.set_option("use_mfma", 1)
+
+
+def test_sample_does_not_alias_with_periodic_data(orc):
+    """Rows that sit exactly on the sampling period carry 5x larger vectors.  An un-jittered strided sample would
+    see only those rows, set a threshold ~5x too high and underflow; the jittered sample must not."""
+    import torch
+    from hyperdb._native import GpuIndex, METRIC_IDS
+    rng = np.random.default_rng(12)
+    n, d, k = 1_000_000, 16, 100
+    V = rng.standard_normal((n, d)).astype(np.float32)
+    ix = GpuIndex(V)
+    try:
+        mid = METRIC_IDS["dot_product"]
+        q = rng.standard_normal((1, d)).astype(np.float32)
+        ix.topk_device(q, k, mid)
+        s_rows = ix.stat("sample_rows")
+        stride = (n // 16) // (s_rows // 16)
+        assert stride > 8
+        tiles = np.arange(n) // 16
+        V[tiles % stride == 0] *= 5.0
+        ix.update(V)
+        idx, sc, st = ix.topk_device(q, k, mid)
+        assert int(st[0].item()) == 0 and ix.stat("path") == 1
+        oi, osc = orc.rank(V, q[0], top_k=k, metric="dot_product")
+        assert list(idx[0].cpu().numpy()) == list(oi)
+    finally:
+        ix.close()
