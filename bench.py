@@ -275,7 +275,7 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "queries/sec, N=10M d=384 fp16 top-100 (single-query stream; p50 latency alongside)",
+            "metric": f"queries/sec, N={args.n // 1_000_000}M d={args.d} {args.dtype} top-{args.k} (single-query stream; p50 latency alongside)",
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "p50_latency_ms": 1e3 * float(np.median(lat)),
             "p99_latency_ms": 1e3 * float(np.percentile(lat, 99)),

@@ -102,8 +102,6 @@ struct hdb_index {
     int64_t mfma_min_q = 8;
     int64_t use_mfma = 1;
     int64_t exact_bytes = (int64_t)1 << 30;
-    int64_t debug_flags = 0;
-    void* dbg_buf = nullptr;
     // stats of the last hdb_topk call
     int64_t st_sample_rows = 0, st_sample_m = 0, st_path = 0, st_chunks = 0, st_mfma = 0;
     // optional HIP-event timing of the dominant kernel (the pass over all of V)
@@ -226,7 +224,6 @@ extern "C" int hdb_set_option(hdb_index* ix, const char* name, int64_t value) {
     else if (!strcmp(name, "mfma_min_q")) ix->mfma_min_q = value;
     else if (!strcmp(name, "use_mfma")) ix->use_mfma = value;
     else if (!strcmp(name, "exact_bytes")) ix->exact_bytes = std::max<int64_t>(1 << 20, value);
-    else if (!strcmp(name, "debug_flags")) ix->debug_flags = value;
     else if (!strcmp(name, "finalize_threads")) hdb_set_finalize_threads((int)value);
     else if (!strcmp(name, "profile")) { ix->profile = value; ix->ev_used = 0; }
     else return fail(HDB_ERR_ARG, std::string("hdb_set_option: unknown option ") + name);
@@ -244,7 +241,6 @@ extern "C" int hdb_get_stat(hdb_index* ix, const char* name, int64_t* value) {
     else if (!strcmp(name, "n")) *value = ix->n;
     else if (!strcmp(name, "ws_bytes")) *value = (int64_t)ix->ws_bytes;
     else if (!strcmp(name, "scan_launches")) *value = (int64_t)(ix->ev_used / 2);
-    else if (!strcmp(name, "debug_buffer")) *value = (int64_t)(uintptr_t)ix->dbg_buf;
     else if (!strcmp(name, "scan_time_ns")) {      // sum over recorded launches; synchronises on the last event
         double total_ms = 0.0;
         for (size_t i = 0; i + 1 < ix->ev_used; i += 2) {
@@ -313,7 +309,6 @@ static void base_args(const hdb_index* ix, ScanArgs& a, const void* Q, int metri
     a.inv_norm = ix->inv_norm; a.mask = ix->mask;
     a.tile_stride = 1; a.ntiles = (ix->n + 15) / 16;
     a.cap = HDB_CAND_CAP;
-    a.dbg = (int32_t)ix->debug_flags;
 }
 
 // One scan launch (VALU, hamming or MFMA flavour) for queries [a.q0, a.q0+cq).
@@ -441,7 +436,6 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     uint32_t* tie_info = b.take<uint32_t>((size_t)cq_max * 4);
     unsigned long long* cand = b.take<unsigned long long>((size_t)cq_max * HDB_CAND_CAP);
     float* sbuf = b.take<float>((size_t)cq_max * (exact && !small ? ld_n : ld_s));
-    ix->dbg_buf = sbuf;
 
     LAUNCH_TRY(hdb_launch_qprep(dev_Q, nq, ix->d, f64, qinv, qsq, qnan, st));
     if (is_ham) {

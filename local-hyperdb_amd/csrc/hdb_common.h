@@ -40,7 +40,6 @@ struct ScanArgs {
     uint32_t cap;
     int32_t nq;             // total number of queries behind Q
     int32_t raw;            // 1: keep NaN scores as NaN (per-metric functions); 0: NaN -> -inf (ranking)
-    int32_t dbg;            // timing-only ablation bits (results are wrong when set): 1 no LDS-DMA, 2 no MFMA, 4 no filter
 };
 
 // ---- strided row sample -------------------------------------------------------------------------
@@ -48,6 +47,7 @@ struct ScanArgs {
 // pseudo-random offset inside each stride window, so that a matrix with periodic structure (rows inserted
 // round-robin by class, ...) cannot alias with the sampling period.  stride == 1 (dense scan) gives jitter 0.
 __device__ __forceinline__ int64_t hdb_tile_index(int64_t t, int64_t stride) {
+    if (stride == 1) return t;                       // dense pass: keep the division off the load path
     const uint32_t h = (uint32_t)t * 2654435761u;
     return t * stride + (int64_t)((h >> 8) % (uint32_t)stride);
 }

@@ -108,24 +108,19 @@ __global__ __launch_bounds__(256) void hdb_scan_kernel(ScanArgs a, int nq_end) {
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) acc[u][qt] = Acc(0);
 
-        auto step = [&](int j) {
-            const int c = l16 + 16 * j;
-            const bool live = NJ > 0 ? true : (c < a.nchunks);
-            const int cc = live ? c : a.nchunks - 1;
-            uint4 raw[4];
-            // non-temporal loads: V is streamed exactly once per query, keeping it out of the caches' LRU
-            // measured +10 % (5.9 -> 6.5 TB/s at N=10M d=384 fp16, 2 workgroups per CU)
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        // one 16-byte chunk of each of the 4 rows: non-temporal (V is streamed exactly once per query)
+        auto load4 = [&](int cc, uint4 (&raw)[4]) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
                 const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p[u] + (int64_t)cc * 16));
                 raw[u] = make_uint4(v.x, v.y, v.z, v.w);
             }
+        };
+        auto fma4 = [&](int cc, bool live, const uint4 (&raw)[4]) {
             Acc x[4][EPC];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                hdb_unpack(raw[u], x[u], (T*)nullptr);
-            }
+            for (int u = 0; u < 4; ++u) hdb_unpack(raw[u], x[u], (T*)nullptr);
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
                 Acc qv[EPC];
@@ -150,10 +145,27 @@ __global__ __launch_bounds__(256) void hdb_scan_kernel(ScanArgs a, int nq_end) {
             }
         };
         if constexpr (NJ > 0) {
+            // rows of exactly NJ*256 bytes: issue ALL loads of the tile (4*NJ x 16 B per lane, up to 3 steps at a
+            // time) before the first use, so that every wave keeps 12 KiB in flight whatever the compiler schedules
+            constexpr int G = (NJ > 3 && QT > 1) ? 3 : NJ;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) step(j);
+            for (int j0 = 0; j0 < NJ; j0 += G) {
+                uint4 raw[G][4];
+#pragma unroll
+                for (int j = 0; j < G; ++j) load4(l16 + 16 * (j0 + j), raw[j]);
+                __builtin_amdgcn_sched_barrier(0);       // keep the loads ahead of every use (hipcc otherwise re-serialises them)
+#pragma unroll
+                for (int j = 0; j < G; ++j) fma4(l16 + 16 * (j0 + j), true, raw[j]);
+            }
         } else {
-            for (int j = 0; j < nj; ++j) step(j);
+            for (int j = 0; j < nj; ++j) {
+                const int c = l16 + 16 * j;
+                const bool live = c < a.nchunks;
+                const int cc = live ? c : a.nchunks - 1;
+                uint4 raw[4];
+                load4(cc, raw);
+                fma4(cc, live, raw);
+            }
         }
         // finish the 16-lane row sums; lane l16==u keeps row u of its group
         const int u_own = hdb_owned_row(l16);
@@ -393,8 +405,9 @@ extern "C" int hdb_launch_scan(const ScanArgs* args, int dtype, int mode, int nq
     a.nchunks = a.row_bytes / 16;
     const bool vec = (a.row_bytes % 16 == 0) && ((reinterpret_cast<uintptr_t>(a.V) & 15) == 0) &&
                      ((size_t)a.d * (elem == 8 ? 8 : 4) <= 60 * 1024);
-    // grid: measured optimum (non-temporal row stream) is 2 workgroups per CU for 768-byte rows, 4 for longer ones
-    const int auto_blocks = (a.nchunks == 48) ? 512 : 1024;
+    // grid: with every wave keeping a whole tile (12-24 KiB) in flight, 2 workgroups (8 waves) per CU is the
+    // measured optimum for the non-temporal row stream (6.8 TB/s at 768-byte rows, 6.2-6.5 at 1536)
+    const int auto_blocks = 512;
     const int blocks = hdb_grid_for(a.ntiles, 4, max_blocks > 0 ? max_blocks : auto_blocks);
     if (dtype == HDB_F16) { if (mode == 0) launch_scan_t<__half, 0>(a, nq_launch, blocks, vec, st); else launch_scan_t<__half, 1>(a, nq_launch, blocks, vec, st); }
     else if (dtype == HDB_F32) { if (mode == 0) launch_scan_t<float, 0>(a, nq_launch, blocks, vec, st); else launch_scan_t<float, 1>(a, nq_launch, blocks, vec, st); }

@@ -8,7 +8,6 @@ from __future__ import annotations
 
 import ctypes
 import os
-import threading
 
 import numpy as np
 import torch  # must be imported before the .so so that ONE libamdhip64 (torch's) serves both
@@ -79,7 +78,6 @@ def _load():
 
 
 _lib = _load()
-_lock = threading.Lock()
 
 
 def lib():
@@ -105,8 +103,6 @@ def require_gpu():
 
 _NP2HDB = {np.dtype(np.float16): HDB_F16, np.dtype(np.float32): HDB_F32, np.dtype(np.float64): HDB_F64}
 _TORCH2HDB = {torch.float16: HDB_F16, torch.float32: HDB_F32, torch.float64: HDB_F64}
-_NP2TORCH = {np.dtype(np.float16): torch.float16, np.dtype(np.float32): torch.float32,
-             np.dtype(np.float64): torch.float64}
 
 
 def _stream_ptr(device):

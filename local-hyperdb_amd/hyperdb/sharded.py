@@ -74,7 +74,6 @@ class ShardedIndex:
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.n_total = n_total
         self.force_exchange = force_exchange and group is not None     # run gather+merge even with one rank (tests)
-        self._host = {}
 
     # -- helpers -------------------------------------------------------------------------------
     def _gather_merge(self, Q, k, metric_id, exact):

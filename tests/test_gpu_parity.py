@@ -49,12 +49,6 @@ def _tol(dtype, metric):
     return 1e-3 if np.dtype(dtype) == np.float16 else 1e-5
 
 
-def _dot_tol(dtype, metric, V=None):
-    # raw dot products of fp32 data: the reference's own sgemv is ~1.6e-5 off exact at |s|~80
-    # (SURVEY.md 8a rule 2) -> relative form already in tol*max(1,|s|); keep 1e-5.
-    return _tol(dtype, metric)
-
-
 # ------------------------------------------------------------------------------------------------
 # 1. the reference's own unit tests, run against the shim (tests/test_ranking_algorithm.py)
 # ------------------------------------------------------------------------------------------------
