@@ -78,6 +78,15 @@ int hdb_index_create(hdb_index** out, const void* dev_V, int64_t n, int32_t d, i
  * matrix lifecycle counterpart of commit_pending / remove_document (hyperdb.py:503-509,:721-728). */
 int hdb_index_update(hdb_index* ix, const void* dev_V, int64_t n, void* stream);
 
+/* Growable matrix (HyperDB.add, hyperdb.py:503-509 grows self.vectors by np.concatenate on every commit):
+ * hdb_index_rebase -- the caller moved the SAME rows to another allocation (capacity doubling); only the borrowed
+ *                     pointer changes, every cache stays valid.
+ * hdb_index_extend -- rows [n_old, new_n) were appended behind the existing rows of the current allocation; the
+ *                     1/||v||, ||v||^2 and NaN caches are extended over the new rows only (O(new rows), not O(N));
+ *                     sign-bit and pearson caches are rebuilt lazily on their next use. */
+int hdb_index_rebase(hdb_index* ix, const void* dev_V);
+int hdb_index_extend(hdb_index* ix, int64_t new_n, void* stream);
+
 void hdb_index_destroy(hdb_index* ix);
 
 /* 1 if the matrix contains a NaN (synchronises `stream` of the create/update call). */

@@ -180,6 +180,46 @@ extern "C" int hdb_index_update(hdb_index* ix, const void* dev_V, int64_t n, voi
     return build_caches(ix, (hipStream_t)stream);
 }
 
+extern "C" int hdb_index_rebase(hdb_index* ix, const void* dev_V) {
+    if (!ix) return fail(HDB_ERR_ARG, "hdb_index_rebase: null index");
+    if (ix->n > 0 && !dev_V) return fail(HDB_ERR_ARG, "hdb_index_rebase: matrix pointer is null");
+    ix->V = dev_V;
+    return HDB_OK;
+}
+
+extern "C" int hdb_index_extend(hdb_index* ix, int64_t new_n, void* stream) {
+    if (!ix) return fail(HDB_ERR_ARG, "hdb_index_extend: null index");
+    if (new_n < ix->n) return fail(HDB_ERR_ARG, "hdb_index_extend: new_n must not shrink the matrix (use hdb_index_update)");
+    if (new_n >= ((int64_t)1 << 32) - 1) return fail(HDB_ERR_ARG, "hdb_index_extend: at most 2^32-2 rows per shard");
+    if (new_n == ix->n) return HDB_OK;
+    if (!ix->V) return fail(HDB_ERR_ARG, "hdb_index_extend: no matrix registered");
+    HIP_TRY(hipSetDevice(ix->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t old_n = ix->n;
+    if (new_n > ix->cache_rows) {                      // grow the per-row caches, keeping the old values
+        const int64_t rows = new_n + new_n / 2 + 64;
+        float *inv2 = nullptr, *sq2 = nullptr;
+        HIP_TRY(hipMalloc((void**)&inv2, rows * sizeof(float)));
+        HIP_TRY(hipMalloc((void**)&sq2, rows * sizeof(float)));
+        if (old_n > 0) {
+            HIP_TRY(hipMemcpyAsync(inv2, ix->inv_norm, old_n * sizeof(float), hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(sq2, ix->sqnorm, old_n * sizeof(float), hipMemcpyDeviceToDevice, st));
+        }
+        HIP_TRY(hipStreamSynchronize(st));
+        if (ix->inv_norm) { HIP_TRY(hipFree(ix->inv_norm)); HIP_TRY(hipFree(ix->sqnorm)); }
+        ix->inv_norm = inv2; ix->sqnorm = sq2; ix->cache_rows = rows;
+    }
+    const size_t elem = ix->dtype == HDB_F16 ? 2 : ix->dtype == HDB_F32 ? 4 : 8;
+    const char* tail = (const char*)ix->V + (size_t)old_n * ix->d * elem;
+    LAUNCH_TRY(hdb_launch_rownorm(tail, new_n - old_n, ix->d, ix->dtype, ix->inv_norm + old_n, ix->sqnorm + old_n, ix->nan_flag, st));
+    ix->n = new_n;
+    ix->bits_valid = false;
+    ix->pscale_valid = false;
+    ix->bias = nullptr; ix->mask = nullptr;            // per-row inputs of the old length no longer apply
+    ix->build_stream = st;
+    return HDB_OK;
+}
+
 extern "C" void hdb_index_destroy(hdb_index* ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);

@@ -32,7 +32,8 @@ HDB_MAX_K = 2048
 NAN_MESSAGE = "Vectors and query_vector should not contain NaN values."   # reference ranking_algorithm.py:151
 
 EXPORTS = (
-    "hdb_version", "hdb_last_error", "hdb_index_create", "hdb_index_update", "hdb_index_destroy",
+    "hdb_version", "hdb_last_error", "hdb_index_create", "hdb_index_update", "hdb_index_rebase", "hdb_index_extend",
+    "hdb_index_destroy",
     "hdb_index_has_nan", "hdb_index_set_bias", "hdb_index_set_row_mask", "hdb_scores", "hdb_topk",
     "hdb_topk_exact", "hdb_merge_topk", "hdb_set_option", "hdb_get_stat", "hdb_recency_bias",
     "hdb_packed_bytes", "hdb_merge_topk_packed",
@@ -55,6 +56,8 @@ def _load():
     lib.hdb_last_error.restype = cp
     lib.hdb_index_create.argtypes = [ctypes.POINTER(vp), vp, i64, i32, ctypes.c_int, ctypes.c_int, i64, vp]
     lib.hdb_index_update.argtypes = [vp, vp, i64, vp]
+    lib.hdb_index_rebase.argtypes = [vp, vp]
+    lib.hdb_index_extend.argtypes = [vp, i64, vp]
     lib.hdb_index_destroy.argtypes = [vp]
     lib.hdb_index_destroy.restype = None
     lib.hdb_index_has_nan.argtypes = [vp, ctypes.POINTER(ctypes.c_int)]
@@ -170,6 +173,37 @@ class GpuIndex:
             self.close()
         except Exception:
             pass
+
+    def append(self, rows):
+        """Append rows behind the stored ones (HyperDB.add): amortised O(new rows).  The device allocation grows
+        by doubling; the library re-points (hdb_index_rebase) and extends its row caches (hdb_index_extend)."""
+        t = to_device_matrix(rows, self.device)
+        if t.dim() == 1:
+            t = t.reshape(1, -1)
+        if t.dim() != 2 or int(t.shape[1]) != self.d:
+            raise ValueError(f"append: rows must have {self.d} columns")
+        if t.dtype != self.V.dtype:
+            t = t.to(self.V.dtype)
+        m = int(t.shape[0])
+        if m == 0:
+            return
+        buf = getattr(self, "_buf", None)
+        if buf is None or buf.data_ptr() != self.V.data_ptr():
+            buf = self.V                                    # first append: the registered tensor is the buffer
+        cap = int(buf.shape[0])
+        if self.n + m > cap:
+            new_cap = max(self.n + m, 2 * cap, 1024)
+            nbuf = torch.empty((new_cap, self.d), dtype=self.V.dtype, device=self.device)
+            nbuf[:self.n].copy_(self.V)
+            buf = nbuf
+            _check(_lib.hdb_index_rebase(self._h, ctypes.c_void_p(buf.data_ptr())), "hdb_index_rebase")
+        buf[self.n:self.n + m].copy_(t)
+        self._buf = buf
+        self.n += m
+        self.V = buf[:self.n]
+        self._bias = self._mask = None
+        self._nan = None
+        _check(_lib.hdb_index_extend(self._h, self.n, _stream_ptr(self.device)), "hdb_index_extend")
 
     def update(self, vectors):
         """Point the handle at a new matrix (after add/remove) and rebuild the row caches."""

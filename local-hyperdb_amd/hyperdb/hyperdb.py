@@ -53,7 +53,7 @@ class HyperDB:
         self.ann_metric, self.n_trees = ann_metric, n_trees          # accepted for compatibility; no ANN is built
         self.device = device
         self.documents, self.source_indices = [], []
-        self.vectors = None
+        self._chunks, self._host_cache = [], None
         self._index = None
         self._cache = OrderedDict()
         self._cache_size = cache_size
@@ -69,7 +69,11 @@ class HyperDB:
         return np.asarray(self.embedding_function(documents))
 
     def add(self, documents, vectors=None, add_timestamp=None):
-        """Append documents with their vectors (hyperdb.py:548-566 without chunking/embedding)."""
+        """Append documents with their vectors (hyperdb.py:548-566 without chunking/embedding).
+
+        The device matrix grows in place (capacity doubling) and only the new rows' caches are computed:
+        amortised O(new rows), where the reference re-concatenates the whole array (hyperdb.py:503-509) and
+        rebuilds the Annoy index (:680) on every commit."""
         if documents is None:
             raise ValueError("documents are required")
         if not isinstance(documents, list):
@@ -81,36 +85,48 @@ class HyperDB:
             vectors = vectors.reshape(1, -1)
         if vectors.ndim != 2 or len(vectors) != len(documents):
             raise ValueError("All vectors must have the same dimension, one per document.")   # hyperdb.py:139-164
+        if self._index is not None and vectors.shape[1] != self._index.d:
+            raise ValueError("All vectors must have the same dimension, one per document.")
         vectors = vectors.astype(self.fp_precision, copy=False)
         start = len(self.documents)
         self.documents = list(self.documents) + list(documents)
         self.source_indices = list(self.source_indices) + list(range(start, start + len(documents)))
-        self.vectors = vectors if self.vectors is None else np.concatenate([self.vectors, vectors], axis=0)
-        self._refresh()
+        self._chunks.append(vectors)
+        self._host_cache = None
+        self.clear_cache()
+        if self._index is None:
+            self._index = GpuIndex(vectors, device=self.device)
+        else:
+            self._index.append(vectors)
 
     def remove_document(self, index):
-        """Drop rows by index or list of indices (hyperdb.py:691-766, matrix part)."""
+        """Drop rows by index or list of indices (hyperdb.py:691-766, matrix part): the surviving rows are
+        compacted on the device (one pass at HBM speed) and the row caches rebuilt; nothing is re-uploaded."""
+        import torch
         drop = np.atleast_1d(np.asarray(index, dtype=np.int64))
         keep = np.ones(len(self.documents), dtype=bool)
         keep[drop] = False
-        self.vectors = self.vectors[keep]
         self.documents = [d for d, k in zip(self.documents, keep) if k]
         self.source_indices = [s for s, k in zip(self.source_indices, keep) if k]
-        self._refresh()
-
-    def _refresh(self):
+        host = self.vectors
+        self._chunks = [host[keep]] if host is not None and keep.any() else []
+        self._host_cache = None
         self.clear_cache()
-        if self.vectors is None or len(self.vectors) == 0:
-            if self._index is not None:
+        if self._index is not None:
+            if not keep.any():
                 self._index.close()
-            self._index = None
-            return
-        if self._index is None or self._index.d != self.vectors.shape[1]:
-            if self._index is not None:
-                self._index.close()
-            self._index = GpuIndex(self.vectors, device=self.device)
-        else:
-            self._index.update(self.vectors)
+                self._index = None
+            else:
+                kept = self._index.V[torch.from_numpy(keep).to(self._index.device)]
+                self._index.update(kept)
+
+    @property
+    def vectors(self):
+        """Host copy of the matrix (what the reference keeps in self.vectors); concatenated lazily."""
+        if self._host_cache is None and self._chunks:
+            self._host_cache = self._chunks[0] if len(self._chunks) == 1 else np.concatenate(self._chunks, axis=0)
+            self._chunks = [self._host_cache]
+        return self._host_cache
 
     def size(self):
         return len(self.documents)
@@ -179,9 +195,9 @@ class HyperDB:
             q = q.reshape(1, -1)
         if q.size == 0:
             raise ValueError("The generated query vector is empty.")
-        if q.shape[1] != self.vectors.shape[1]:
+        if q.shape[1] != self._index.d:
             raise ValueError(f"The dimension of the query_vector ({q.shape[1]}) must match the dimension of the vectors "
-                             f"in the database ({self.vectors.shape[1]}).")
+                             f"in the database ({self._index.d}).")
         return q
 
     def _row_mask(self, filters):
@@ -210,7 +226,7 @@ class HyperDB:
 
     # ---------------------------------------------------------------- query (hyperdb.py:1429-1586)
     def _execute(self, Q, top_k, return_similarities, filters, recency_bias, timestamp_key, metric):
-        if self.vectors is None or len(self.vectors) == 0 or not self.documents:
+        if self._index is None or not self.documents:
             raise Exception("The database is empty. Cannot proceed with the query.")
         if metric not in _METRICS:
             raise ValueError(f"Invalid metric '{metric}'. Supported: " + ", ".join(f"'{m}'" for m in _METRICS))
@@ -255,7 +271,7 @@ class HyperDB:
             return self._cache[key]
         self.cache_misses += 1
         try:
-            if self.vectors is None or len(self.vectors) == 0 or not self.documents:
+            if self._index is None or not self.documents:
                 raise Exception("The database is empty. Cannot proceed with the query.")
             Q = self._query_vectors(query_input)
             if len(Q) != 1:

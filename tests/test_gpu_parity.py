@@ -702,3 +702,29 @@ def test_sample_does_not_alias_with_periodic_data(orc):
         assert list(idx[0].cpu().numpy()) == list(oi)
     finally:
         ix.close()
+
+
+def test_growable_index_append_matches_full_rebuild(orc):
+    """hdb_index_rebase / hdb_index_extend: appended rows get their caches incrementally; answers must equal a
+    fresh registration of the concatenated matrix, for every cached quantity (norms, sign bits, pearson scales)."""
+    from hyperdb._native import GpuIndex, METRIC_IDS
+    rng = np.random.default_rng(31)
+    V = rng.standard_normal((30_000, 64)).astype(np.float32).astype(np.float16)
+    q = rng.standard_normal((3, 64)).astype(np.float16)
+    ix = GpuIndex(V[:500])
+    try:
+        ix.topk(q, 5, METRIC_IDS["hamming_distance"])            # builds the sign-bit cache, must be invalidated later
+        for lo, hi in ((500, 501), (501, 9_000), (9_000, 30_000)):      # grows past the capacity several times
+            ix.append(V[lo:hi])
+            assert ix.n == hi
+        fresh = GpuIndex(V)
+        for metric in ("cosine_similarity", "euclidean_metric", "hamming_distance", "pearson_correlation", "dot_product"):
+            i1, s1 = ix.topk(q, 50, METRIC_IDS[metric])
+            i2, s2 = fresh.topk(q, 50, METRIC_IDS[metric])
+            assert np.array_equal(i1, i2) and np.array_equal(s1, s2), metric
+        fresh.close()
+        bad = V[:3].copy(); bad[1, 7] = np.nan
+        ix.append(bad)
+        assert ix.has_nan
+    finally:
+        ix.close()
