@@ -122,6 +122,12 @@ int hdb_scores(hdb_index* ix, const void* dev_q, int metric, float* dev_out, voi
 int hdb_topk(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, int metric,
              int64_t* dev_idx, float* dev_score, int32_t* dev_status, void* stream);
 
+/* hdb_topk + copy of the packed result record ([nq*k int64][nq*k f32][nq i32], hdb_packed_bytes) into host memory
+ * (pinned memory recommended) + stream synchronisation, in one call: what one HyperDB.query() needs.  Queries whose
+ * sampled threshold failed are re-run through the exact path before returning; on return every status word is 0
+ * except HDB_Q_NAN.  Saves the caller-side allocations and the extra host round trips of doing this in Python. */
+int hdb_topk_host(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, int metric, void* host_record, void* stream);
+
 /* Same contract, but by materialising all n scores per query and radix-selecting them:
  * always exact, any tie pattern, any k <= HDB_MAX_K; dev_status is written as 0. */
 int hdb_topk_exact(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, int metric,

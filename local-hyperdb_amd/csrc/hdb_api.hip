@@ -92,6 +92,9 @@ struct hdb_index {
     // borrowed
     const float* bias = nullptr;
     const uint8_t* mask = nullptr;
+    // device copy of the result record of hdb_topk_host (owned)
+    char* rec = nullptr;
+    size_t rec_bytes = 0;
     // scratch (owned)
     char* ws = nullptr;
     size_t ws_bytes = 0;
@@ -230,6 +233,7 @@ extern "C" void hdb_index_destroy(hdb_index* ix) {
     if (ix->bits) (void)hipFree(ix->bits);
     if (ix->pscale) (void)hipFree(ix->pscale);
     if (ix->ws) (void)hipFree(ix->ws);
+    if (ix->rec) (void)hipFree(ix->rec);
     for (hipEvent_t e : ix->ev_pool) (void)hipEventDestroy(e);
     delete ix;
 }
@@ -581,6 +585,43 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
 extern "C" int hdb_topk(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, int metric, int64_t* dev_idx,
                         float* dev_score, int32_t* dev_status, void* stream) {
     return topk_impl(ix, dev_Q, nq, k, metric, dev_idx, dev_score, dev_status, stream, false);
+}
+
+extern "C" int64_t hdb_packed_bytes(int32_t nq, int32_t k);
+
+extern "C" int hdb_topk_host(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, int metric, void* host_record, void* stream) {
+    if (!ix || !host_record) return fail(HDB_ERR_ARG, "hdb_topk_host: null argument");
+    if (nq <= 0 || k <= 0) return fail(HDB_ERR_ARG, "hdb_topk_host: nq and k must be positive");
+    HIP_TRY(hipSetDevice(ix->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t bytes = (size_t)hdb_packed_bytes(nq, k);
+    if (bytes > ix->rec_bytes) {
+        if (ix->rec) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(ix->rec)); ix->rec = nullptr; }
+        HIP_TRY(hipMalloc((void**)&ix->rec, bytes * 2));
+        ix->rec_bytes = bytes * 2;
+    }
+    int64_t* d_idx = reinterpret_cast<int64_t*>(ix->rec);
+    float* d_sc = reinterpret_cast<float*>(ix->rec + (size_t)nq * k * 8);
+    int32_t* d_st = reinterpret_cast<int32_t*>(ix->rec + (size_t)nq * k * 12);
+    int rc = topk_impl(ix, dev_Q, nq, k, metric, d_idx, d_sc, d_st, stream, false);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(host_record, ix->rec, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const int32_t* h_st = reinterpret_cast<const int32_t*>(static_cast<const char*>(host_record) + (size_t)nq * k * 12);
+    bool any_bad = false;
+    for (int q = 0; q < nq; ++q) any_bad |= (h_st[q] & (HDB_Q_UNDERFLOW | HDB_Q_OVERFLOW)) != 0;
+    if (!any_bad) return HDB_OK;
+    // rare: re-run the failed queries one by one through the exact path, straight into their slots of the record
+    const size_t qbytes = (size_t)ix->d * (ix->dtype == HDB_F64 ? 8 : 4);
+    for (int q = 0; q < nq; ++q) {
+        if (!(h_st[q] & (HDB_Q_UNDERFLOW | HDB_Q_OVERFLOW))) continue;
+        rc = topk_impl(ix, static_cast<const char*>(dev_Q) + (size_t)q * qbytes, 1, k, metric, d_idx + (size_t)q * k,
+                       d_sc + (size_t)q * k, d_st + q, stream, true);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(host_record, ix->rec, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return HDB_OK;
 }
 
 extern "C" int hdb_topk_exact(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, int metric, int64_t* dev_idx,

@@ -36,7 +36,7 @@ EXPORTS = (
     "hdb_index_destroy",
     "hdb_index_has_nan", "hdb_index_set_bias", "hdb_index_set_row_mask", "hdb_scores", "hdb_topk",
     "hdb_topk_exact", "hdb_merge_topk", "hdb_set_option", "hdb_get_stat", "hdb_recency_bias",
-    "hdb_packed_bytes", "hdb_merge_topk_packed",
+    "hdb_packed_bytes", "hdb_merge_topk_packed", "hdb_topk_host",
 )
 
 
@@ -70,6 +70,7 @@ def _load():
     lib.hdb_set_option.argtypes = [vp, cp, i64]
     lib.hdb_get_stat.argtypes = [vp, cp, ctypes.POINTER(i64)]
     lib.hdb_recency_bias.argtypes = [vp, i64, ctypes.c_double, ctypes.c_double, vp, ctypes.c_int, vp]
+    lib.hdb_topk_host.argtypes = [vp, vp, i32, i32, ctypes.c_int, vp, vp]
     lib.hdb_packed_bytes.argtypes = [i32, i32]
     lib.hdb_merge_topk_packed.argtypes = [vp, i32, i32, i32, vp, vp, vp, ctypes.c_int, vp]
     for name in EXPORTS:
@@ -335,27 +336,29 @@ class GpuIndex:
                   ctypes.c_void_p(base + nq * k * 8), ctypes.c_void_p(base + nq * k * 12),
                   _stream_ptr(self.device)), "hdb_topk")
 
-    def topk(self, Q, k, metric_id):
-        """Top-k of a query batch on the host: (int64 [nq,k], float32 [nq,k]).  One packed record, one
-        D2H copy.  Queries whose sampled threshold failed (status != 0) are re-run through the exact path."""
+    def topk_views(self, Q, k, metric_id):
+        """One C call (hdb_topk_host): kernels + D2H of the packed record into a cached pinned buffer + sync + the
+        rare exact re-run.  Returns numpy VIEWS (idx int64 [nq,k], score float32 [nq,k], status int32 [nq]) that are
+        overwritten by the next call with the same (nq, k)."""
         qt = self._query_tensor(Q, batched=True)
         nq = int(qt.shape[0])
-        rec = torch.empty(packed_bytes(nq, k), dtype=torch.uint8, device=self.device)
-        self.topk_packed(qt, k, metric_id, rec)
-        idx, sc, st = record_to_host(rec, nq, k)
+        nb = packed_bytes(nq, k)
+        host = _pinned.get(nb)
+        if host is None:
+            host = torch.empty(nb, dtype=torch.uint8, pin_memory=True)
+            _pinned[nb] = host
+        _check(_lib.hdb_topk_host(self._h, ctypes.c_void_p(qt.data_ptr()), nq, int(k), int(metric_id),
+                                  ctypes.c_void_p(host.data_ptr()), _stream_ptr(self.device)), "hdb_topk_host")
+        h = host.numpy()
+        return (h[:nq * k * 8].view(np.int64).reshape(nq, k), h[nq * k * 8:nq * k * 12].view(np.float32).reshape(nq, k),
+                h[nq * k * 12:nq * k * 12 + nq * 4].view(np.int32))
+
+    def topk(self, Q, k, metric_id):
+        """Top-k of a query batch on the host: (int64 [nq,k], float32 [nq,k]) (copies)."""
+        idx, sc, st = self.topk_views(Q, k, metric_id)
         if (st & Q_NAN).any():
             raise ValueError(NAN_MESSAGE)
-        idx, sc = idx.copy(), sc.copy()
-        bad = np.nonzero(st & (Q_UNDERFLOW | Q_OVERFLOW))[0]
-        if bad.size:
-            sel = torch.from_numpy(bad).to(self.device)
-            qb = qt.index_select(0, sel)
-            rec2 = torch.empty(packed_bytes(int(bad.size), k), dtype=torch.uint8, device=self.device)
-            self.topk_packed(qb, k, metric_id, rec2, exact=True)
-            i2, s2, _ = record_to_host(rec2, int(bad.size), k)
-            idx[bad] = i2
-            sc[bad] = s2
-        return idx, sc
+        return idx.copy(), sc.copy()
 
 
 def packed_bytes(nq, k):

@@ -51,6 +51,9 @@ class HipEngine:
         from . import _native
         return _native.record_to_host(record, nq, k)
 
+    def topk_host(self, Q, k, metric_id):
+        return self.index.topk_views(Q, k, metric_id)
+
     def select_queries(self, Q, which):
         return Q.index_select(0, torch.as_tensor(which, device=Q.device))
 
@@ -96,6 +99,11 @@ class ShardedIndex:
         """Global top-k of a (nq, d) query batch: (int64 [nq,k], float32 [nq,k]) numpy, same on all ranks."""
         if Q.dim() == 1:
             Q = Q.reshape(1, -1)
+        if self.world == 1 and not self.force_exchange and hasattr(self.engine, "topk_host"):
+            idx_v, sc_v, st_v = self.engine.topk_host(Q, k, metric_id)      # one C call, fallback included
+            if (st_v & 4).any():
+                raise ValueError("Vectors and query_vector should not contain NaN values.")
+            return idx_v.copy(), sc_v.copy()
         idx_v, sc_v, st_v = self._gather_merge(Q, k, metric_id, exact=False)
         if (st_v & 4).any():
             raise ValueError("Vectors and query_vector should not contain NaN values.")
