@@ -134,7 +134,8 @@ int hdb_topk_exact(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, int 
                    int64_t* dev_idx, float* dev_score, int32_t* dev_status, void* stream);
 
 /* Merge `parts` per-shard top-k lists (the all-gathered [parts][nq][k] buffers of the row-sharded
- * index) into the global top-k per query, same ordering rule.  Index -1 entries are ignored. */
+ * index) into the global top-k per query, same ordering rule.  Every part list must be ordered as hdb_topk writes
+ * it: score descending, row ascending, unused slots (index -1) at the end. */
 int hdb_merge_topk(const int64_t* dev_idx_parts, const float* dev_score_parts, int32_t parts,
                    int32_t nq, int32_t k, int64_t* dev_idx, float* dev_score, int device, void* stream);
 

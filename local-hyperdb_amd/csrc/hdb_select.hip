@@ -373,39 +373,51 @@ __global__ __launch_bounds__(1024) void hdb_finalize_kernel(const unsigned long 
 // (contiguous row sharding) and each list is already in canonical order, so position p*k+i is a
 // valid tie-break for equal scores.
 // ------------------------------------------------------------------------------------------------
+// Rank-by-binary-search merge: every part list is already sorted (score descending, row ascending), so the global
+// rank of entry i of part p is  i + sum over the other parts of #{entries that sort before it}: parts-1 binary
+// searches over keys in LDS (row ids are read from global memory only on key ties), no sort and no
+// synchronisation after the keys are staged.  One workgroup per query, one thread per entry.
 __global__ __launch_bounds__(1024) void hdb_merge_kernel(const char* idx_base, int64_t idx_stride, const char* score_base,
                                                          int64_t score_stride, const char* status_base, int64_t status_stride,
                                                          int parts, int nq, uint32_t k, int64_t* idx_out, float* score_out,
                                                          int32_t* status_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long buf[];
+    uint32_t* keys = reinterpret_cast<uint32_t*>(buf);            // [parts][k], 0 for empty slots (below every real key)
     const int q = blockIdx.x;
     const uint32_t total = (uint32_t)parts * k;
-    int P = 64;
-    while ((uint32_t)P < total) P <<= 1;
-    for (int i = threadIdx.x; i < P; i += blockDim.x) {
-        unsigned long long e = 0ull;
-        if ((uint32_t)i < total) {
-            const int p = i / k, j = i - p * k;
-            const int64_t off = (int64_t)q * k + j;
-            const int64_t id = reinterpret_cast<const int64_t*>(idx_base + (int64_t)p * idx_stride)[off];
-            const float sc = reinterpret_cast<const float*>(score_base + (int64_t)p * score_stride)[off];
-            if (id >= 0) e = hdb_pack(sc, (uint32_t)i);   // key(-inf) > 0, so real rows never look like padding
-        }
-        buf[i] = e;
+    for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) {
+        const uint32_t p = i / k, j = i - p * k;
+        const int64_t off = (int64_t)q * k + j;
+        const int64_t id = reinterpret_cast<const int64_t*>(idx_base + (int64_t)p * idx_stride)[off];
+        const float sc = reinterpret_cast<const float*>(score_base + (int64_t)p * score_stride)[off];
+        keys[i] = id >= 0 ? hdb_f2key(hdb_canon(sc)) : 0u;
     }
+    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) { idx_out[(int64_t)q * k + i] = -1; score_out[(int64_t)q * k + i] = -INFINITY; }
     __syncthreads();
-    hdb_bitonic_desc(buf, P);
-    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
-        const unsigned long long e = buf[i];
-        if (e != 0ull) {
-            const uint32_t pos = 0xFFFFFFFFu - (uint32_t)(e & 0xFFFFFFFFull);
-            const int p = pos / k, j = pos - p * k;
-            const int64_t off = (int64_t)q * k + j;
-            idx_out[(int64_t)q * k + i] = reinterpret_cast<const int64_t*>(idx_base + (int64_t)p * idx_stride)[off];
-            score_out[(int64_t)q * k + i] = reinterpret_cast<const float*>(score_base + (int64_t)p * score_stride)[off];
-        } else {
-            idx_out[(int64_t)q * k + i] = -1;
-            score_out[(int64_t)q * k + i] = -INFINITY;
+    for (uint32_t i = threadIdx.x; i < total; i += blockDim.x) {
+        const uint32_t key = keys[i];
+        if (key == 0u) continue;
+        const uint32_t p = i / k, j = i - p * k;
+        const int64_t off = (int64_t)q * k + j;
+        const int64_t my_id = reinterpret_cast<const int64_t*>(idx_base + (int64_t)p * idx_stride)[off];
+        uint32_t rank = j;
+        for (uint32_t pp = 0; pp < (uint32_t)parts && rank < k; ++pp) {
+            if (pp == p) continue;
+            const uint32_t* lst = keys + pp * k;
+            const int64_t* ids = reinterpret_cast<const int64_t*>(idx_base + (int64_t)pp * idx_stride) + (int64_t)q * k;
+            // lists are (key descending, row ascending): count the entries that sort before (key, my_id)
+            uint32_t lo = 0, hi = k;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                const uint32_t v = lst[mid];
+                const bool before = v > key || (v == key && ids[mid] < my_id);
+                if (before) lo = mid + 1; else hi = mid;
+            }
+            rank += lo;
+        }
+        if (rank < k) {
+            idx_out[(int64_t)q * k + rank] = my_id;
+            score_out[(int64_t)q * k + rank] = reinterpret_cast<const float*>(score_base + (int64_t)p * score_stride)[off];
         }
     }
     if (threadIdx.x == 0 && status_out) {
@@ -462,9 +474,9 @@ extern "C" int hdb_launch_finalize(const unsigned long long* cand, const uint32_
 extern "C" int hdb_launch_merge(const void* idx_base, int64_t idx_stride, const void* score_base, int64_t score_stride,
                                 const void* status_base, int64_t status_stride, int parts, int nq, uint32_t k,
                                 int64_t* idx_out, float* score_out, int32_t* status_out, void* stream) {
-    size_t P = 64;
-    while (P < (size_t)parts * k) P <<= 1;
-    hipLaunchKernelGGL(hdb_merge_kernel, dim3(nq), dim3(1024), P * 8, (hipStream_t)stream, (const char*)idx_base, idx_stride,
+    const size_t lds = ((size_t)parts * k * 4 + 15) / 16 * 16;
+    const unsigned threads = (size_t)parts * k >= 1024 ? 1024 : 256;
+    hipLaunchKernelGGL(hdb_merge_kernel, dim3(nq), dim3(threads), lds, (hipStream_t)stream, (const char*)idx_base, idx_stride,
                        (const char*)score_base, score_stride, (const char*)status_base, status_stride, parts, nq, k, idx_out,
                        score_out, status_out);
     return (int)hipGetLastError();

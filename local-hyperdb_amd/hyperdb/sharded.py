@@ -32,13 +32,19 @@ class HipEngine:
     def __init__(self, index):
         self.index = index
         self.device = index.device
+        self._records = {}
 
     def packed_bytes(self, nq, k):
         from . import _native
         return _native.packed_bytes(nq, k)
 
-    def new_record(self, nbytes):
-        return torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+    def new_record(self, nbytes, slot=0):
+        """Device scratch for one exchange record; cached per (slot, size) so a query allocates nothing."""
+        key = (slot, int(nbytes))
+        buf = self._records.get(key)
+        if buf is None:
+            buf = self._records[key] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        return buf
 
     def topk_packed(self, Q, k, metric_id, record, exact=False):
         self.index.topk_packed(Q, k, metric_id, record, exact=exact)
@@ -84,13 +90,13 @@ class ShardedIndex:
         eng = self.engine
         nq = int(Q.shape[0])
         nb = eng.packed_bytes(nq, k)
-        rec = eng.new_record(nb)
+        rec = eng.new_record(nb, 0)
         eng.topk_packed(Q, k, metric_id, rec, exact=exact)
         if self.world == 1 and not self.force_exchange:
             return eng.record_to_host(rec, nq, k)               # already the global answer
-        gathered = eng.new_record(nb * self.world)
+        gathered = eng.new_record(nb * self.world, 1)
         dist.all_gather_into_tensor(gathered, rec, group=self.group)
-        merged = eng.new_record(nb)
+        merged = eng.new_record(nb, 2)
         eng.merge_packed_into(gathered, self.world, nq, k, merged)
         return eng.record_to_host(merged, nq, k)
 

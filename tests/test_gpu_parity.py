@@ -422,6 +422,38 @@ def test_shard_merge_equals_global(orc):
         s.close()
 
 
+@pytest.mark.parametrize("parts,k,levels", [(8, 100, 7), (8, 1024, 3), (2, 5, 2), (5, 333, 50), (1, 64, 4)])
+def test_merge_ties_padding_and_interleaved_rows(parts, k, levels):
+    """hdb_merge_topk against a host merge: heavy score ties across parts, row ids interleaved between parts
+    (tie order must follow the row id, not the part number), ragged lists padded with -1."""
+    import torch
+    from hyperdb._native import merge_topk
+    rng = np.random.default_rng(parts * 1000 + k)
+    nq = 4
+    idx = np.full((parts, nq, k), -1, np.int64)
+    sc = np.full((parts, nq, k), -np.inf, np.float32)
+    want_i = np.full((nq, k), -1, np.int64)
+    want_s = np.full((nq, k), -np.inf, np.float32)
+    for q in range(nq):
+        rows = rng.permutation(parts * k * 2)[:parts * k].reshape(parts, k)       # interleaved, unique
+        allp = []
+        for p in range(parts):
+            m = k if (p + q) % 3 else int(rng.integers(0, k + 1))                    # ragged
+            s = rng.integers(0, levels, size=m).astype(np.float32) * 0.25 - 1.0
+            if m and q == 1:
+                s[rng.integers(0, m)] = -np.inf                                      # a real -inf score with a valid row
+            order = np.lexsort((rows[p, :m], -s))
+            idx[p, q, :m], sc[p, q, :m] = rows[p, :m][order], s[order]
+            allp += list(zip(-s, rows[p, :m]))
+        allp.sort()
+        top = allp[:k]
+        want_i[q, :len(top)] = [r for _, r in top]
+        want_s[q, :len(top)] = [-v for v, _ in top]
+    gi, gs = merge_topk(torch.from_numpy(idx).cuda(), torch.from_numpy(sc).cuda(), k)
+    assert np.array_equal(gi.cpu().numpy(), want_i)
+    assert np.array_equal(gs.cpu().numpy(), want_s)
+
+
 def test_rank_batch_matches_oracle(ranking, orc):
     rng = np.random.default_rng(21)
     V = rng.standard_normal((30_000, 384)).astype(np.float32).astype(np.float16)

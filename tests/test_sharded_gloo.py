@@ -33,7 +33,7 @@ class OracleEngine:
     def packed_bytes(self, nq, k):
         return self.nat.packed_bytes(nq, k)        # the C function: layout comes from the library
 
-    def new_record(self, nbytes):
+    def new_record(self, nbytes, slot=0):
         return torch.zeros(nbytes, dtype=torch.uint8)
 
     def _views(self, record, nq, k):
