@@ -43,6 +43,7 @@ int hdb_launch_qcentre(const void* Q, int nq, int d, bool f64, void* Qc, float* 
 int hdb_launch_recency(const double* ts, int64_t n, double rb, double ts_max, float* out, void* stream);
 int hdb_mfma_supported(int dtype, int d, int metric);
 int hdb_mfma_tile_rows(int d);
+void hdb_set_mfma_variant(int v);
 int hdb_launch_mfma_scan(const ScanArgs* args, int mode, int nq_launch, const void* q16, const float* sqnorm,
                          const float* qsq, int max_blocks, void* stream);
 int hdb_launch_q_to_f16(const float* Q, int nq, int d, void* q16, void* stream);
@@ -269,6 +270,7 @@ extern "C" int hdb_set_option(hdb_index* ix, const char* name, int64_t value) {
     else if (!strcmp(name, "use_mfma")) ix->use_mfma = value;
     else if (!strcmp(name, "exact_bytes")) ix->exact_bytes = std::max<int64_t>(1 << 20, value);
     else if (!strcmp(name, "finalize_threads")) hdb_set_finalize_threads((int)value);
+    else if (!strcmp(name, "mfma_variant")) hdb_set_mfma_variant((int)value);
     else if (!strcmp(name, "profile")) { ix->profile = value; ix->ev_used = 0; }
     else return fail(HDB_ERR_ARG, std::string("hdb_set_option: unknown option ") + name);
     return HDB_OK;

@@ -28,6 +28,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define HDB_MFMA_CB 1024            // LDS candidate list entries per workgroup
+#ifndef HDB_PF_QT2
+#define HDB_PF_QT2 2
+#endif
 
 #define HDB_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define HDB_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -64,7 +67,7 @@ template <> struct MfmaShape<16> {
 // METRIC: 0 dot, 1 cosine (aux0 = 1/||v||), 2 euclidean similarity (aux0 = ||v||^2)
 // Fragment maps (lane l):  MF=32: row/query l&31, k = 16s + 8(l>>5) + j, C reg e -> row (e&3) + 8(e>>2) + 4(l>>5)
 //                          MF=16: row/query l&15, k = 32s + 8(l>>4) + j, C reg e -> row 4(l>>4) + e
-template <int MF, int D, int R, int MODE, int METRIC, bool HAS_BIAS>
+template <int MF, int QT, int D, int R, int MODE, int METRIC, bool HAS_BIAS>
 __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float16* __restrict__ q16,
                                                        const float* __restrict__ aux0g, const float* __restrict__ qsq,
                                                        int nq_end) {
@@ -80,6 +83,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
     constexpr bool AUX0 = METRIC != 0;
     constexpr int NLOADA = NG;
     constexpr int NLOADB = NG + (AUX0 ? 1 : 0) + (HAS_BIAS ? 1 : 0);     // B waves also stage the per-row aux values
+    constexpr int QPW = MF * QT;                // queries per wave (QT query tiles share every A fragment)
     static_assert(R % MF == 0 && R <= 64 && (R * CPR) % 512 == 0 && D % 128 == 0 && KS % NG == 0, "tile geometry");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -94,27 +98,31 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
     const int h = lane / MF;                    // which 8-element k-chunk of the step (0..CPS-1)
 
     // ---- this wave's queries --------------------------------------------------------------------
-    const int qw0 = a.q0 + blockIdx.y * (8 * MF) + w * MF;
+    const int qw0 = a.q0 + blockIdx.y * (8 * QPW) + w * QPW;
     const bool wave_active = qw0 < nq_end;
-    const int q = qw0 + rl;
-    const bool q_ok = q < nq_end;
-    const int ql = q - a.q0;
-    half8 Bq[KS];
-    {
-        const int qq = q_ok ? q : (nq_end - 1);
+    bool q_ok[QT];
+    int ql[QT];
+    half8 Bq[QT][KS];
+    float thr_l[QT], qinv_l[QT], qsq_l[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int q = qw0 + qt * MF + rl;
+        q_ok[qt] = q < nq_end;
+        ql[qt] = q - a.q0;
+        const int qq = q_ok[qt] ? q : (nq_end - 1);
         const uint4* src = reinterpret_cast<const uint4*>(q16 + (int64_t)qq * D + 8 * h);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             uint4 v = src[CPS * s];
-            if (!q_ok) v = make_uint4(0, 0, 0, 0);
-            Bq[s] = *reinterpret_cast<half8*>(&v);
+            if (!q_ok[qt]) v = make_uint4(0, 0, 0, 0);
+            Bq[qt][s] = *reinterpret_cast<half8*>(&v);
         }
-    }
-    float thr_l = 0.f, qinv_l = 1.f, qsq_l = 0.f;
-    if (q_ok) {
-        if (MODE == 1) thr_l = a.thr[ql];
-        if (METRIC == 1) qinv_l = a.qinv[q];
-        if (METRIC == 2) qsq_l = qsq[q];
+        thr_l[qt] = 0.f; qinv_l[qt] = 1.f; qsq_l[qt] = 0.f;
+        if (q_ok[qt]) {
+            if (MODE == 1) thr_l[qt] = a.thr[ql[qt]];
+            if (METRIC == 1) qinv_l[qt] = a.qinv[q];
+            if (METRIC == 2) qsq_l[qt] = qsq[q];
+        }
     }
     if (tid < 4) ctl[tid] = 0;
 
@@ -126,7 +134,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
     // Then A stages its half of tile i+2 right after the barrier while B already multiplies, and B stages its
     // half after its MFMA phase while A finishes -- the two waves of a SIMD never issue LDS-DMA (~90 cycles of
     // blocked issue per 1 KiB piece) at the same time.  Otherwise (HBM-bound) everyone stages right away.
-    const bool heavy = (nq_end - (a.q0 + (int)blockIdx.y * (8 * MF))) > 4 * MF;
+    const bool heavy = (nq_end - (a.q0 + (int)blockIdx.y * (8 * QPW))) > 4 * QPW;
 
     // ---- staging geometry (per lane, fixed for the whole kernel) -----------------------------------
     int g_off[NG];
@@ -203,15 +211,19 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
     auto grp_row = [&](int rt, int g) { return MF == 32 ? rt * 32 + 8 * g + 4 * h : rt * 16 + 4 * h; };
 
     // threshold in the domain the epilogue compares in (see below); +inf for padding lanes
-    float thr_cmp = INFINITY;
-    if (MODE == 1 && q_ok) {
-        if (METRIC == 1 && !HAS_BIAS) { const float tc = thr_l / qinv_l; thr_cmp = tc - fabsf(tc) * 1e-6f; }
-        else thr_cmp = thr_l;
+    float thr_cmp[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        thr_cmp[qt] = INFINITY;
+        if (MODE == 1 && q_ok[qt]) {
+            if (METRIC == 1 && !HAS_BIAS) { const float tc = thr_l[qt] / qinv_l[qt]; thr_cmp[qt] = tc - fabsf(tc) * 1e-6f; }
+            else thr_cmp[qt] = thr_l[qt];
+        }
     }
 
     // Filter, second half: group maxima (v_max3) let the common no-hit case finish in ~25 VALU
     // instructions; survivors go to the workgroup's LDS list.  `tv` holds comparable values (below).
-    auto filter = [&](const Acc (&tv)[RT], int64_t row0) {
+    auto filter1 = [&](const Acc (&tv)[RT], int64_t row0, const float thr_cmp, const float qinv_l, const int ql) {
         float gm[RT][NGRP];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -258,9 +270,14 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
         }
     };
 
+    auto filter = [&](const Acc (&tv)[QT][RT], int64_t row0) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) filter1(tv[qt], row0, thr_cmp[qt], qinv_l[qt], ql[qt]);
+    };
+
     const int chk_shift = ntiles >= 65536 ? 4 : 0;
     const int64_t chk_mask = (1 << chk_shift) - 1;
-    Acc acc[RT];
+    Acc acc[QT][RT];
     int64_t row0_prev = 0;
     int st_cur = 0;
     for (int64_t i = 0; i < my_tiles; ++i, t_cur += gstep) {
@@ -288,9 +305,11 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
             const int64_t row0 = hdb_tile_index(t_cur, tstride) * R;
             if (MODE == 1 && grpB && i > 0) filter(acc, row0_prev);        // deferred epilogue of tile i-1
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt)
+            for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-                for (int e = 0; e < 4 * NGRP; ++e) acc[rt][e] = 0.f;
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int e = 0; e < 4 * NGRP; ++e) acc[qt][rt][e] = 0.f;
 
             // A fragments: LDS reads issued two k-steps ahead of the MFMAs that consume them.  The reads
             // and their counted waits are inline asm so that hipcc cannot sink a read next to its use
@@ -298,7 +317,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
             // lgkmcnt(n*RT) = "all but the n*RT newest LDS ops are back" = the oldest pending step's fragments;
             // stray scalar loads can only make that wait longer, never shorter.
             const unsigned int sb_addr = smem_addr + (unsigned int)(st_cur * STAGE) + rd_base;
-            constexpr int PF = 3;                              // k-steps of LDS prefetch (PF+1 fragment sets)
+            constexpr int PF = HDB_PF_QT2 > 0 && QT == 2 ? HDB_PF_QT2 : 3;   // k-steps of LDS prefetch (PF+1 fragment sets)
             half8 abuf[PF + 1][RT];
             auto fetch = [&](int s, half8 (&dst)[RT]) {
                 const unsigned int ad = sb_addr + ((unsigned int)(16 * CPS * s) ^ hx);
@@ -330,7 +349,9 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
                 const int pend = (KS - 1 - s) < PF ? (KS - 1 - s) : PF;       // steps still in flight behind step s
                 wait_frag(pend, abuf[s % (PF + 1)]);
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt) acc[rt] = Shape::mma(abuf[s % (PF + 1)][rt], Bq[s], acc[rt]);
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) acc[qt][rt] = Shape::mma(abuf[s % (PF + 1)][rt], Bq[qt][s], acc[qt][rt]);
             }
 
             // ---- epilogue, first half: turn the dot products into the values that are stored (MODE 0) or
@@ -350,18 +371,21 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
                         const float aj[4] = {av.x, av.y, av.z, av.w};
                         const float bj[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float dot = acc[rt][4 * g + j];
-                            float x;
-                            if (METRIC == 0) x = dot + bj[j];
-                            else if (METRIC == 1) {
-                                if (MODE == 1 && !HAS_BIAS) x = dot * aj[j];
-                                else x = HAS_BIAS ? fmaf(dot * aj[j], qinv_l, bj[j]) : dot * aj[j] * qinv_l;
-                            } else {
-                                const float d2 = fmaxf(aj[j] + qsq_l - 2.f * dot, 0.f);
-                                x = 1.f / (1.f + sqrtf(d2)) + (HAS_BIAS ? bj[j] : 0.f);
+                        for (int qt = 0; qt < QT; ++qt) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float dot = acc[qt][rt][4 * g + j];
+                                float x;
+                                if (METRIC == 0) x = dot + bj[j];
+                                else if (METRIC == 1) {
+                                    if (MODE == 1 && !HAS_BIAS) x = dot * aj[j];
+                                    else x = HAS_BIAS ? fmaf(dot * aj[j], qinv_l[qt], bj[j]) : dot * aj[j] * qinv_l[qt];
+                                } else {
+                                    const float d2 = fmaxf(aj[j] + qsq_l[qt] - 2.f * dot, 0.f);
+                                    x = 1.f / (1.f + sqrtf(d2)) + (HAS_BIAS ? bj[j] : 0.f);
+                                }
+                                acc[qt][rt][4 * g + j] = x;
                             }
-                            acc[rt][4 * g + j] = x;
                         }
                     }
                 }
@@ -373,15 +397,18 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
                     for (int g = 0; g < NGRP; ++g) {
                         const int rl0 = grp_row(rt, g);
                         const int64_t rowg = row0 + rl0;
-                        float sj[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) sj[j] = hdb_canon(acc[rt][4 * g + j]);
-                        if (q_ok) {
-                            float* dst = a.scores + (int64_t)ql * a.ld + (t_cur * R + rl0);
-                            if (rowg + 3 < n_rows) *reinterpret_cast<float4*>(dst) = make_float4(sj[0], sj[1], sj[2], sj[3]);
-                            else {
+                        for (int qt = 0; qt < QT; ++qt) {
+                            float sj[4];
 #pragma unroll
-                                for (int j = 0; j < 4; ++j) if (rowg + j < n_rows) dst[j] = sj[j];
+                            for (int j = 0; j < 4; ++j) sj[j] = hdb_canon(acc[qt][rt][4 * g + j]);
+                            if (q_ok[qt]) {
+                                float* dst = a.scores + (int64_t)ql[qt] * a.ld + (t_cur * R + rl0);
+                                if (rowg + 3 < n_rows) *reinterpret_cast<float4*>(dst) = make_float4(sj[0], sj[1], sj[2], sj[3]);
+                                else {
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) if (rowg + j < n_rows) dst[j] = sj[j];
+                                }
                             }
                         }
                     }
@@ -437,9 +464,9 @@ static size_t mfma_lds_bytes(int stage_bytes) {
     return (size_t)3 * stage_bytes + 3 * 2 * 64 * 4 + (size_t)HDB_MFMA_CB * 8 + (size_t)HDB_MFMA_CB * 2 + 64;
 }
 
-template <int MF, int D, int R, int MODE, int METRIC, bool HAS_BIAS>
+template <int MF, int QT, int D, int R, int MODE, int METRIC, bool HAS_BIAS>
 static int launch_one(const ScanArgs& a, const void* q16, const float* aux0, const float* qsq, int nq_launch, int blocks, hipStream_t st) {
-    auto kern = hdb_mfma_kernel<MF, D, R, MODE, METRIC, HAS_BIAS>;
+    auto kern = hdb_mfma_kernel<MF, QT, D, R, MODE, METRIC, HAS_BIAS>;
     const size_t lds = mfma_lds_bytes(R * D * 2);
     static bool attr_done = false;          // per instantiation
     if (!attr_done) {
@@ -447,27 +474,27 @@ static int launch_one(const ScanArgs& a, const void* q16, const float* aux0, con
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    const dim3 grid(blocks, (nq_launch + 8 * MF - 1) / (8 * MF));
+    const dim3 grid(blocks, (nq_launch + 8 * MF * QT - 1) / (8 * MF * QT));
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a, (const _Float16*)q16, aux0, qsq, a.q0 + nq_launch);
     return (int)hipGetLastError();
 }
 
-template <int MF, int D, int R, int MODE>
+template <int MF, int QT, int D, int R, int MODE>
 static int launch_metric(const ScanArgs& a, const void* q16, const float* sqnorm, const float* qsq, int nq_launch, int blocks, hipStream_t st) {
     const bool b = a.bias != nullptr;
-    if (a.metric == HDB_DOT) return b ? launch_one<MF, D, R, MODE, 0, true>(a, q16, nullptr, qsq, nq_launch, blocks, st)
-                                      : launch_one<MF, D, R, MODE, 0, false>(a, q16, nullptr, qsq, nq_launch, blocks, st);
-    if (a.metric == HDB_COSINE) return b ? launch_one<MF, D, R, MODE, 1, true>(a, q16, a.inv_norm, qsq, nq_launch, blocks, st)
-                                         : launch_one<MF, D, R, MODE, 1, false>(a, q16, a.inv_norm, qsq, nq_launch, blocks, st);
-    if (a.metric == HDB_EUCLIDEAN) return b ? launch_one<MF, D, R, MODE, 2, true>(a, q16, sqnorm, qsq, nq_launch, blocks, st)
-                                            : launch_one<MF, D, R, MODE, 2, false>(a, q16, sqnorm, qsq, nq_launch, blocks, st);
+    if (a.metric == HDB_DOT) return b ? launch_one<MF, QT, D, R, MODE, 0, true>(a, q16, nullptr, qsq, nq_launch, blocks, st)
+                                      : launch_one<MF, QT, D, R, MODE, 0, false>(a, q16, nullptr, qsq, nq_launch, blocks, st);
+    if (a.metric == HDB_COSINE) return b ? launch_one<MF, QT, D, R, MODE, 1, true>(a, q16, a.inv_norm, qsq, nq_launch, blocks, st)
+                                         : launch_one<MF, QT, D, R, MODE, 1, false>(a, q16, a.inv_norm, qsq, nq_launch, blocks, st);
+    if (a.metric == HDB_EUCLIDEAN) return b ? launch_one<MF, QT, D, R, MODE, 2, true>(a, q16, sqnorm, qsq, nq_launch, blocks, st)
+                                            : launch_one<MF, QT, D, R, MODE, 2, false>(a, q16, sqnorm, qsq, nq_launch, blocks, st);
     return (int)hipErrorNotSupported;
 }
 
-template <int MF, int D, int R>
+template <int MF, int QT, int D, int R>
 static int launch_mode(const ScanArgs& a, int mode, const void* q16, const float* sqnorm, const float* qsq, int nq_launch, int blocks, hipStream_t st) {
-    if (mode == 0) return launch_metric<MF, D, R, 0>(a, q16, sqnorm, qsq, nq_launch, blocks, st);
-    return launch_metric<MF, D, R, 1>(a, q16, sqnorm, qsq, nq_launch, blocks, st);
+    if (mode == 0) return launch_metric<MF, QT, D, R, 0>(a, q16, sqnorm, qsq, nq_launch, blocks, st);
+    return launch_metric<MF, QT, D, R, 1>(a, q16, sqnorm, qsq, nq_launch, blocks, st);
 }
 
 // Geometry table: rows per LDS stage (stage = R*d*2 bytes <= 48 KiB, three stages + lists <= 160 KiB).
@@ -486,6 +513,12 @@ extern "C" int hdb_mfma_supported(int dtype, int d, int metric) {
            (metric == HDB_DOT || metric == HDB_COSINE || metric == HDB_EUCLIDEAN);
 }
 
+// d=384, more than 128 queries: 16 = 16x16x32 with two query tiles per wave (default: the same FLOPs and LDS
+// traffic as the 32x32x16 form, but the chip holds a higher clock on this shape: 1.78-1.85 ms against 2.07-2.25 ms
+// for N=10M, Q=256), 32 = 32x32x16 with one query tile per wave (kept for A/B measurements).
+static int g_mfma_variant = 16;
+extern "C" void hdb_set_mfma_variant(int v) { if (v == 16 || v == 32) g_mfma_variant = v; }
+
 extern "C" int hdb_mfma_queries_per_pass(int d, int nq) { return (d == 384 && nq > 128) ? 256 : 128; }
 
 // a.ntiles / a.tile_stride are in units of hdb_mfma_tile_rows(d) rows here.
@@ -498,14 +531,15 @@ extern "C" int hdb_launch_mfma_scan(const ScanArgs* args, int mode, int nq_launc
     if (max_blocks > 0 && max_blocks < blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
     switch (a.d) {
-        case 128: return launch_mode<16, 128, 64>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
-        case 256: return launch_mode<16, 256, 64>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
+        case 128: return launch_mode<16, 1, 128, 64>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
+        case 256: return launch_mode<16, 1, 256, 64>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
         case 384:
-            if (nq_launch > 128) return launch_mode<32, 384, 64>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
-            return launch_mode<16, 384, 64>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
-        case 512: return launch_mode<16, 512, 32>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
-        case 640: return launch_mode<16, 640, 32>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
-        case 768: return launch_mode<16, 768, 32>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
+            if (nq_launch > 128 && g_mfma_variant == 32) return launch_mode<32, 1, 384, 64>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
+            if (nq_launch > 128) return launch_mode<16, 2, 384, 64>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
+            return launch_mode<16, 1, 384, 64>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
+        case 512: return launch_mode<16, 1, 512, 32>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
+        case 640: return launch_mode<16, 1, 640, 32>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
+        case 768: return launch_mode<16, 1, 768, 32>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
         default: return (int)hipErrorNotSupported;
     }
 }

@@ -13,7 +13,7 @@ import numpy as np
 import torch  # must be imported before the .so so that ONE libamdhip64 (torch's) serves both
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libhyperdb_hip.so")
+LIB_PATH = os.environ.get("HYPERDB_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libhyperdb_hip.so")
 
 HDB_F16, HDB_F32, HDB_F64 = 0, 1, 2
 METRIC_IDS = {
