@@ -106,6 +106,7 @@ struct hdb_index {
     int64_t mfma_min_q = 8;
     int64_t use_mfma = 1;
     int64_t exact_bytes = (int64_t)1 << 30;
+    int64_t host_direct = 1;          // hdb_topk_host: kernels write a pinned host record themselves (no D2H copy)
     // stats of the last hdb_topk call
     int64_t st_sample_rows = 0, st_sample_m = 0, st_path = 0, st_chunks = 0, st_mfma = 0;
     // optional HIP-event timing of the dominant kernel (the pass over all of V)
@@ -271,6 +272,7 @@ extern "C" int hdb_set_option(hdb_index* ix, const char* name, int64_t value) {
     else if (!strcmp(name, "exact_bytes")) ix->exact_bytes = std::max<int64_t>(1 << 20, value);
     else if (!strcmp(name, "finalize_threads")) hdb_set_finalize_threads((int)value);
     else if (!strcmp(name, "mfma_variant")) hdb_set_mfma_variant((int)value);
+    else if (!strcmp(name, "host_direct")) ix->host_direct = value;
     else if (!strcmp(name, "profile")) { ix->profile = value; ix->ev_used = 0; }
     else return fail(HDB_ERR_ARG, std::string("hdb_set_option: unknown option ") + name);
     return HDB_OK;
@@ -597,17 +599,29 @@ extern "C" int hdb_topk_host(hdb_index* ix, const void* dev_Q, int32_t nq, int32
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st = (hipStream_t)stream;
     const size_t bytes = (size_t)hdb_packed_bytes(nq, k);
-    if (bytes > ix->rec_bytes) {
-        if (ix->rec) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(ix->rec)); ix->rec = nullptr; }
-        HIP_TRY(hipMalloc((void**)&ix->rec, bytes * 2));
-        ix->rec_bytes = bytes * 2;
+    // Pinned (device-visible) host memory: the last kernels of the pipeline store the record there themselves and the
+    // D2H copy disappears from the critical path; anything else goes through a device record and one hipMemcpyAsync.
+    bool direct = false;
+    if (ix->host_direct) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, host_record) == hipSuccess) direct = attr.type == hipMemoryTypeHost && attr.devicePointer == host_record;
+        else (void)hipGetLastError();
     }
-    int64_t* d_idx = reinterpret_cast<int64_t*>(ix->rec);
-    float* d_sc = reinterpret_cast<float*>(ix->rec + (size_t)nq * k * 8);
-    int32_t* d_st = reinterpret_cast<int32_t*>(ix->rec + (size_t)nq * k * 12);
+    char* rec = static_cast<char*>(host_record);
+    if (!direct) {
+        if (bytes > ix->rec_bytes) {
+            if (ix->rec) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(ix->rec)); ix->rec = nullptr; }
+            HIP_TRY(hipMalloc((void**)&ix->rec, bytes * 2));
+            ix->rec_bytes = bytes * 2;
+        }
+        rec = ix->rec;
+    }
+    int64_t* d_idx = reinterpret_cast<int64_t*>(rec);
+    float* d_sc = reinterpret_cast<float*>(rec + (size_t)nq * k * 8);
+    int32_t* d_st = reinterpret_cast<int32_t*>(rec + (size_t)nq * k * 12);
     int rc = topk_impl(ix, dev_Q, nq, k, metric, d_idx, d_sc, d_st, stream, false);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(host_record, ix->rec, bytes, hipMemcpyDeviceToHost, st));
+    if (!direct) HIP_TRY(hipMemcpyAsync(host_record, rec, bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const int32_t* h_st = reinterpret_cast<const int32_t*>(static_cast<const char*>(host_record) + (size_t)nq * k * 12);
     bool any_bad = false;
@@ -615,13 +629,15 @@ extern "C" int hdb_topk_host(hdb_index* ix, const void* dev_Q, int32_t nq, int32
     if (!any_bad) return HDB_OK;
     // rare: re-run the failed queries one by one through the exact path, straight into their slots of the record
     const size_t qbytes = (size_t)ix->d * (ix->dtype == HDB_F64 ? 8 : 4);
+    std::vector<char> bad(nq);
+    for (int q = 0; q < nq; ++q) bad[q] = (h_st[q] & (HDB_Q_UNDERFLOW | HDB_Q_OVERFLOW)) != 0;     // the re-run rewrites h_st
     for (int q = 0; q < nq; ++q) {
-        if (!(h_st[q] & (HDB_Q_UNDERFLOW | HDB_Q_OVERFLOW))) continue;
+        if (!bad[q]) continue;
         rc = topk_impl(ix, static_cast<const char*>(dev_Q) + (size_t)q * qbytes, 1, k, metric, d_idx + (size_t)q * k,
                        d_sc + (size_t)q * k, d_st + q, stream, true);
         if (rc) return rc;
     }
-    HIP_TRY(hipMemcpyAsync(host_record, ix->rec, bytes, hipMemcpyDeviceToHost, st));
+    if (!direct) HIP_TRY(hipMemcpyAsync(host_record, rec, bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return HDB_OK;
 }

@@ -344,6 +344,26 @@ __global__ __launch_bounds__(1024) void hdb_finalize_kernel(const unsigned long 
     __syncthreads();
     uint32_t ns = nc;
     if (nc > 512 && kk < nc / 2) ns = hdb_preselect(buf, nc, kk, hist, scratch, ctl);
+    const uint32_t nout = nc < kk ? nc : kk;             // entries that exist
+    if (ns <= 256) {
+        // Few survivors (the usual case: ~kk plus one histogram bin): rank sort.  Packed entries are distinct, so the
+        // number of larger entries is the output position; one pass of LDS broadcast reads, no barrier.
+        for (uint32_t i = nout + threadIdx.x; i < k; i += blockDim.x) { idx_out[(int64_t)q * k + i] = -1; score_out[(int64_t)q * k + i] = -INFINITY; }
+        if (threadIdx.x < ns) {
+            const unsigned long long mine = buf[threadIdx.x];
+            uint32_t rank = 0;
+            uint32_t j = 0;
+            for (; j + 2 <= ns; j += 2) {
+                const ulonglong2 pr = *reinterpret_cast<const ulonglong2*>(buf + j);
+                rank += (pr.x > mine) + (pr.y > mine);
+            }
+            if (j < ns) rank += buf[j] > mine;
+            if (rank < nout) {
+                idx_out[(int64_t)q * k + rank] = row_base + (int64_t)(0xFFFFFFFFu - (uint32_t)(mine & 0xFFFFFFFFull));
+                score_out[(int64_t)q * k + rank] = hdb_key2f((uint32_t)(mine >> 32));
+            }
+        }
+    } else {
     int P = 64;
     while ((uint32_t)P < ns) P <<= 1;
     for (int i = ns + threadIdx.x; i < P; i += blockDim.x) buf[i] = 0ull;
@@ -358,6 +378,7 @@ __global__ __launch_bounds__(1024) void hdb_finalize_kernel(const unsigned long 
             idx_out[(int64_t)q * k + i] = -1;
             score_out[(int64_t)q * k + i] = -INFINITY;
         }
+    }
     }
     if (threadIdx.x == 0 && status) {
         int32_t st = 0;
