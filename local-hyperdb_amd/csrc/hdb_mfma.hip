@@ -382,7 +382,9 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
                                     else x = HAS_BIAS ? fmaf(dot * aj[j], qinv_l[qt], bj[j]) : dot * aj[j] * qinv_l[qt];
                                 } else {
                                     const float d2 = fmaxf(aj[j] + qsq_l[qt] - 2.f * dot, 0.f);
-                                    x = 1.f / (1.f + sqrtf(d2)) + (HAS_BIAS ? bj[j] : 0.f);
+                                    // v_sqrt_f32 / v_rcp_f32 (1 ulp each): the IEEE expansions of sqrtf and the division
+                                    // cost ~25 VALU per score, on every row x query, for a result needed to 1e-3
+                                    x = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_sqrtf(d2)) + (HAS_BIAS ? bj[j] : 0.f);
                                 }
                                 acc[qt][rt][4 * g + j] = x;
                             }
