@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32"])
     ap.add_argument("--metric", default="cosine_similarity")
     ap.add_argument("--batch-q", type=int, default=256, help="batched leg (config 3); 0 disables")
-    ap.add_argument("--batch-steps", type=int, default=10)
+    ap.add_argument("--batch-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=200_000)
     ap.add_argument("--extra", default="", help="comma list of extra BASELINE configs to time after the headline: c2,c5")

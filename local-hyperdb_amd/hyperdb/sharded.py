@@ -33,6 +33,7 @@ class HipEngine:
         self.index = index
         self.device = index.device
         self._records = {}
+        self._host = {}
 
     def packed_bytes(self, nq, k):
         from . import _native
@@ -56,6 +57,19 @@ class HipEngine:
     def record_to_host(self, record, nq, k):
         from . import _native
         return _native.record_to_host(record, nq, k)
+
+    def merge_packed_to_host(self, gathered, parts, nq, k):
+        """Merge straight into a pinned host record (the merge kernel stores over PCIe itself: no D2H copy)."""
+        from . import _native
+        nb = _native.packed_bytes(nq, k)
+        host = self._host.get(nb)
+        if host is None:
+            host = self._host[nb] = torch.empty(nb, dtype=torch.uint8, pin_memory=True)
+        _native.merge_topk_packed_into(gathered, parts, nq, k, host)
+        torch.cuda.current_stream(self.device).synchronize()
+        h = host.numpy()
+        return (h[:nq * k * 8].view(np.int64).reshape(nq, k), h[nq * k * 8:nq * k * 12].view(np.float32).reshape(nq, k),
+                h[nq * k * 12:nq * k * 12 + nq * 4].view(np.int32))
 
     def topk_host(self, Q, k, metric_id):
         return self.index.topk_views(Q, k, metric_id)
@@ -96,6 +110,8 @@ class ShardedIndex:
             return eng.record_to_host(rec, nq, k)               # already the global answer
         gathered = eng.new_record(nb * self.world, 1)
         dist.all_gather_into_tensor(gathered, rec, group=self.group)
+        if hasattr(eng, "merge_packed_to_host"):
+            return eng.merge_packed_to_host(gathered, self.world, nq, k)
         merged = eng.new_record(nb, 2)
         eng.merge_packed_into(gathered, self.world, nq, k, merged)
         return eng.record_to_host(merged, nq, k)
