@@ -506,6 +506,7 @@ extern "C" int hdb_mfma_tile_rows(int d) {
     switch (d) {
         case 128: case 256: case 384: return 64;
         case 512: case 640: case 768: return 32;
+        case 1024: case 1536: return 16;
         default: return 0;
     }
 }
@@ -542,6 +543,8 @@ extern "C" int hdb_launch_mfma_scan(const ScanArgs* args, int mode, int nq_launc
         case 512: return launch_mode<16, 1, 512, 32>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
         case 640: return launch_mode<16, 1, 640, 32>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
         case 768: return launch_mode<16, 1, 768, 32>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
+        case 1024: return launch_mode<16, 1, 1024, 16>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
+        case 1536: return launch_mode<16, 1, 1536, 16>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
         default: return (int)hipErrorNotSupported;
     }
 }
