@@ -21,7 +21,7 @@
 extern "C" {
 int hdb_launch_scan(const ScanArgs* args, int dtype, int mode, int nq_launch, int max_blocks, void* stream);
 int hdb_launch_rownorm(const void* V, int64_t n, int d, int dtype, float* inv_norm, float* sqnorm, int* nan_flag, void* stream);
-int hdb_launch_qprep(const void* Q, int nq, int d, bool f64, float* qinv, float* qsq, int* qnan, void* stream);
+int hdb_launch_qprep(const void* Q, int nq, int d, bool f64, float* qinv, float* qsq, int* qnan, void* q16, void* stream);
 int hdb_launch_signpack(const void* V, int64_t n, int d, int dtype, int64_t npad, uint32_t* bits, void* stream);
 int hdb_launch_qsign(const void* Q, int nq, int d, bool f64, int W, uint32_t* qbits, void* stream);
 int hdb_launch_hamming(const ScanArgs* args, int mode, int nq_launch, const uint32_t* bits, int64_t npad, int W,
@@ -103,7 +103,7 @@ struct hdb_index {
     int64_t max_blocks = 0;           // 0 = automatic (row scan: 2-4 workgroups per CU, see hdb_launch_scan)
     int64_t force_exact = 0;
     int64_t sample_target = 0;        // 0 = automatic
-    int64_t mfma_min_q = 8;
+    int64_t mfma_min_q = 1;
     int64_t use_mfma = 1;
     int64_t exact_bytes = (int64_t)1 << 30;
     int64_t host_direct = 1;          // hdb_topk_host: kernels write a pinned host record themselves (no D2H copy)
@@ -386,7 +386,7 @@ extern "C" int hdb_scores(hdb_index* ix, const void* dev_q, int metric, float* d
     float* qinv = b.take<float>(1); float* qsq = b.take<float>(1); int* qnan = b.take<int>(1);
     uint32_t* qbits = b.take<uint32_t>(W);
     void* qc = b.take<double>(ix->d);
-    LAUNCH_TRY(hdb_launch_qprep(dev_q, 1, ix->d, ix->dtype == HDB_F64, qinv, qsq, qnan, st));
+    LAUNCH_TRY(hdb_launch_qprep(dev_q, 1, ix->d, ix->dtype == HDB_F64, qinv, qsq, qnan, nullptr, st));
     if (is_bits_metric(metric)) {
         rc = ensure_bits(ix, st); if (rc) return rc;
         LAUNCH_TRY(hdb_launch_qsign(dev_q, 1, ix->d, ix->dtype == HDB_F64, W, qbits, st));
@@ -485,7 +485,9 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     unsigned long long* cand = b.take<unsigned long long>((size_t)cq_max * HDB_CAND_CAP);
     float* sbuf = b.take<float>((size_t)cq_max * (exact && !small ? ld_n : ld_s));
 
-    LAUNCH_TRY(hdb_launch_qprep(dev_Q, nq, ix->d, f64, qinv, qsq, qnan, st));
+    // the MFMA scan multiplies with fp16 queries: written by the same kernel (pearson converts its centred copy later)
+    const bool q16_in_prep = mfma && !is_pearson && !full_sort;
+    LAUNCH_TRY(hdb_launch_qprep(dev_Q, nq, ix->d, f64, qinv, qsq, qnan, q16_in_prep ? q16 : nullptr, st));
     if (is_ham) {
         rc = ensure_bits(ix, st); if (rc) return rc;
         LAUNCH_TRY(hdb_launch_qsign(dev_Q, nq, ix->d, f64, W, qbits, st));
@@ -513,7 +515,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
         float* sc1 = b2.take<float>((size_t)ld_n);
         uint32_t* work = b2.take<uint32_t>((size_t)n * 4);
         void* temp = b2.take<char>(tb);
-        LAUNCH_TRY(hdb_launch_qprep(dev_Q, nq, ix->d, f64, qinv2, qsq2, qnan2, st));
+        LAUNCH_TRY(hdb_launch_qprep(dev_Q, nq, ix->d, f64, qinv2, qsq2, qnan2, nullptr, st));
         if (is_ham) LAUNCH_TRY(hdb_launch_qsign(dev_Q, nq, ix->d, f64, W, qbits2, st));
         const void* Q2 = dev_Q;
         if (is_pearson) { LAUNCH_TRY(hdb_launch_qcentre(dev_Q, nq, ix->d, f64, qc2, qinv2, st)); Q2 = qc2; }
@@ -530,7 +532,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
         if (dev_status) HIP_TRY(hipMemsetAsync(dev_status, 0, (size_t)nq * sizeof(int32_t), st));
         return HDB_OK;
     }
-    bool q16_ready = false;
+    bool q16_ready = q16_in_prep;
     ix->st_sample_rows = s_rows; ix->st_sample_m = m; ix->st_chunks = 0;
     ix->st_path = small ? 0 : (exact ? 2 : 1);
     ix->st_mfma = mfma ? 1 : 0;
