@@ -21,7 +21,7 @@
 extern "C" {
 int hdb_launch_scan(const ScanArgs* args, int dtype, int mode, int nq_launch, int max_blocks, void* stream);
 int hdb_launch_rownorm(const void* V, int64_t n, int d, int dtype, float* inv_norm, float* sqnorm, int* nan_flag, void* stream);
-int hdb_launch_qprep(const void* Q, int nq, int d, bool f64, float* qinv, float* qsq, int* qnan, void* q16, void* stream);
+int hdb_launch_qprep(const void* Q, int nq, int d, bool f64, float* qinv, float* qsq, int* qnan, void* q16, float* qscl, void* stream);
 int hdb_launch_signpack(const void* V, int64_t n, int d, int dtype, int64_t npad, uint32_t* bits, void* stream);
 int hdb_launch_qsign(const void* Q, int nq, int d, bool f64, int W, uint32_t* qbits, void* stream);
 int hdb_launch_hamming(const ScanArgs* args, int mode, int nq_launch, const uint32_t* bits, int64_t npad, int W,
@@ -45,8 +45,8 @@ int hdb_mfma_supported(int dtype, int d, int metric);
 int hdb_mfma_tile_rows(int d);
 void hdb_set_mfma_variant(int v);
 int hdb_launch_mfma_scan(const ScanArgs* args, int mode, int nq_launch, const void* q16, const float* sqnorm,
-                         const float* qsq, int max_blocks, void* stream);
-int hdb_launch_q_to_f16(const float* Q, int nq, int d, void* q16, void* stream);
+                         const float* qsq, const float* qscl, int max_blocks, void* stream);
+int hdb_launch_q_to_f16(const float* Q, int nq, int d, void* q16, float* qscl, void* stream);
 int hdb_sort_temp_bytes(int64_t n, size_t* bytes);
 int hdb_launch_full_sort(const float* scores, int64_t n, int64_t k, int64_t row_base, uint32_t* work, void* temp, size_t temp_bytes,
                          int64_t* idx_out, float* score_out, void* stream);
@@ -360,13 +360,13 @@ static void base_args(const hdb_index* ix, ScanArgs& a, const void* Q, int metri
 }
 
 // One scan launch (VALU, hamming or MFMA flavour) for queries [a.q0, a.q0+cq).
-struct QueryBufs { const float* qinv; const float* qsq; const uint32_t* qbits; const void* q16; };
+struct QueryBufs { const float* qinv; const float* qsq; const uint32_t* qbits; const void* q16; const float* qscl; };
 static int run_scan(hdb_index* ix, ScanArgs& a, int mode, int cq, const QueryBufs& qb, bool mfma, hipStream_t st) {
     a.qinv = qb.qinv;
     if (is_bits_metric(a.metric)) {
         LAUNCH_TRY(hdb_launch_hamming(&a, mode, cq, ix->bits, ix->bits_npad, ix->W, qb.qbits, st));
     } else if (mfma) {
-        LAUNCH_TRY(hdb_launch_mfma_scan(&a, mode, cq, qb.q16, ix->sqnorm, qb.qsq, (int)ix->max_blocks, st));
+        LAUNCH_TRY(hdb_launch_mfma_scan(&a, mode, cq, qb.q16, ix->sqnorm, qb.qsq, qb.qscl, (int)ix->max_blocks, st));
     } else {
         LAUNCH_TRY(hdb_launch_scan(&a, ix->dtype, mode, cq, (int)ix->max_blocks, st));
     }
@@ -386,7 +386,7 @@ extern "C" int hdb_scores(hdb_index* ix, const void* dev_q, int metric, float* d
     float* qinv = b.take<float>(1); float* qsq = b.take<float>(1); int* qnan = b.take<int>(1);
     uint32_t* qbits = b.take<uint32_t>(W);
     void* qc = b.take<double>(ix->d);
-    LAUNCH_TRY(hdb_launch_qprep(dev_q, 1, ix->d, ix->dtype == HDB_F64, qinv, qsq, qnan, nullptr, st));
+    LAUNCH_TRY(hdb_launch_qprep(dev_q, 1, ix->d, ix->dtype == HDB_F64, qinv, qsq, qnan, nullptr, nullptr, st));
     if (is_bits_metric(metric)) {
         rc = ensure_bits(ix, st); if (rc) return rc;
         LAUNCH_TRY(hdb_launch_qsign(dev_q, 1, ix->d, ix->dtype == HDB_F64, W, qbits, st));
@@ -400,7 +400,7 @@ extern "C" int hdb_scores(hdb_index* ix, const void* dev_q, int metric, float* d
     a.mask = nullptr;                   // per-metric functions score every row, no bias (reference :24-147)
     a.raw = 1;                          // ... and return NaN where the reference does (pearson, jaccard)
     a.scores = dev_out; a.ld = ix->n;
-    QueryBufs qb{qinv, qsq, qbits, nullptr};
+    QueryBufs qb{qinv, qsq, qbits, nullptr, nullptr};
     return run_scan(ix, a, 0, 1, qb, false, st);
 }
 
@@ -463,7 +463,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     cq_max = std::min(cq_max, (int)nq);
 
     size_t need = 0;
-    need += 3 * align_up((size_t)nq * 4, 256) + 1024;                        // qinv, qsq, qnan
+    need += 4 * align_up((size_t)nq * 4, 256) + 1024;                        // qinv, qsq, qnan, qscl
     need += align_up((size_t)nq * W * 4, 256);                               // qbits
     need += align_up((size_t)nq * ix->d * 2, 256);                           // fp16 queries (MFMA)
     need += align_up((size_t)nq * ix->d * 8, 256);                           // centred queries (pearson)
@@ -475,7 +475,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     int rc = ensure_ws(ix, need);
     if (rc) return rc;
     Bump b(ix->ws, ix->ws_bytes);
-    float* qinv = b.take<float>(nq); float* qsq = b.take<float>(nq); int* qnan = b.take<int>(nq);
+    float* qinv = b.take<float>(nq); float* qsq = b.take<float>(nq); int* qnan = b.take<int>(nq); float* qscl = b.take<float>(nq);
     uint32_t* qbits = b.take<uint32_t>((size_t)nq * W);
     void* q16 = b.take<uint16_t>((size_t)nq * ix->d);
     void* qc = b.take<double>((size_t)nq * ix->d);
@@ -487,7 +487,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
 
     // the MFMA scan multiplies with fp16 queries: written by the same kernel (pearson converts its centred copy later)
     const bool q16_in_prep = mfma && !is_pearson && !full_sort;
-    LAUNCH_TRY(hdb_launch_qprep(dev_Q, nq, ix->d, f64, qinv, qsq, qnan, q16_in_prep ? q16 : nullptr, st));
+    LAUNCH_TRY(hdb_launch_qprep(dev_Q, nq, ix->d, f64, qinv, qsq, qnan, q16_in_prep ? q16 : nullptr, qscl, st));
     if (is_ham) {
         rc = ensure_bits(ix, st); if (rc) return rc;
         LAUNCH_TRY(hdb_launch_qsign(dev_Q, nq, ix->d, f64, W, qbits, st));
@@ -508,20 +508,20 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
         const size_t base_need = need;
         rc = ensure_ws(ix, base_need + extra); if (rc) return rc;
         Bump b2(ix->ws, ix->ws_bytes);
-        float* qinv2 = b2.take<float>(nq); float* qsq2 = b2.take<float>(nq); int* qnan2 = b2.take<int>(nq);
+        float* qinv2 = b2.take<float>(nq); float* qsq2 = b2.take<float>(nq); int* qnan2 = b2.take<int>(nq); (void)b2.take<float>(nq);
         uint32_t* qbits2 = b2.take<uint32_t>((size_t)nq * W);
         (void)b2.take<uint16_t>((size_t)nq * ix->d);
         void* qc2 = b2.take<double>((size_t)nq * ix->d);
         float* sc1 = b2.take<float>((size_t)ld_n);
         uint32_t* work = b2.take<uint32_t>((size_t)n * 4);
         void* temp = b2.take<char>(tb);
-        LAUNCH_TRY(hdb_launch_qprep(dev_Q, nq, ix->d, f64, qinv2, qsq2, qnan2, nullptr, st));
+        LAUNCH_TRY(hdb_launch_qprep(dev_Q, nq, ix->d, f64, qinv2, qsq2, qnan2, nullptr, nullptr, st));
         if (is_ham) LAUNCH_TRY(hdb_launch_qsign(dev_Q, nq, ix->d, f64, W, qbits2, st));
         const void* Q2 = dev_Q;
         if (is_pearson) { LAUNCH_TRY(hdb_launch_qcentre(dev_Q, nq, ix->d, f64, qc2, qinv2, st)); Q2 = qc2; }
         ix->st_path = 3; ix->st_mfma = 0; ix->st_chunks = nq;
         for (int q0 = 0; q0 < nq; ++q0) {
-            QueryBufs qb{qinv2, qsq2, qbits2, nullptr};
+            QueryBufs qb{qinv2, qsq2, qbits2, nullptr, nullptr};
             ScanArgs s2; base_args(ix, s2, Q2, metric_eff);
             if (is_pearson) s2.inv_norm = ix->pscale;
             s2.q0 = q0; s2.bias = ix->bias; s2.scores = sc1; s2.ld = ld_n;
@@ -540,8 +540,8 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     for (int q0 = 0; q0 < nq; q0 += cq_max) {
         const int cq = std::min(cq_max, nq - q0);
         ix->st_chunks++;
-        if (mfma && !q16_ready) { LAUNCH_TRY(hdb_launch_q_to_f16((const float*)Qeff, nq, ix->d, q16, st)); q16_ready = true; }
-        QueryBufs qb{qinv, qsq, qbits, q16};
+        if (mfma && !q16_ready) { LAUNCH_TRY(hdb_launch_q_to_f16((const float*)Qeff, nq, ix->d, q16, qscl, st)); q16_ready = true; }
+        QueryBufs qb{qinv, qsq, qbits, q16, qscl};
         ScanArgs a; base_args(ix, a, Qeff, metric_eff);
         if (is_pearson) a.inv_norm = ix->pscale;
         a.q0 = q0; a.bias = ix->bias;

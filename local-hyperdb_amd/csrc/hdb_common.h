@@ -42,6 +42,19 @@ struct ScanArgs {
     int32_t raw;            // 1: keep NaN scores as NaN (per-metric functions); 0: NaN -> -inf (ranking)
 };
 
+// ---- fp16 copy of a query for the matrix pipe ----------------------------------------------------------
+// Power-of-two scale that puts the largest magnitude of a query in [2^14, 2^15): an fp32 element above 65504 would
+// otherwise become inf in fp16 and one below 6e-5 a subnormal.  Exact, and undone for free in the kernel epilogue
+// (1/scale rides on the per-query multiplier).  Queries that already are fp16 values keep all their bits.
+__device__ __forceinline__ float hdb_q16_scale(float amax) {
+    if (!(amax > 0.f) || !(amax < INFINITY)) return 1.f;
+    int ex = 0;
+    (void)frexpf(amax, &ex);                                  // amax = m * 2^ex, m in [0.5, 1)
+    int sh = 15 - ex;
+    sh = sh < -100 ? -100 : (sh > 100 ? 100 : sh);
+    return ldexpf(1.f, sh);
+}
+
 // ---- strided row sample -------------------------------------------------------------------------
 // Sample tile t of a strided sample sits at tile index t*stride + jitter(t), jitter in [0, stride): a fixed
 // pseudo-random offset inside each stride window, so that a matrix with periodic structure (rows inserted

@@ -69,7 +69,7 @@ template <> struct MfmaShape<16> {
 //                          MF=16: row/query l&15, k = 32s + 8(l>>4) + j, C reg e -> row 4(l>>4) + e
 template <int MF, int QT, int D, int R, int MODE, int METRIC, bool HAS_BIAS>
 __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float16* __restrict__ q16,
-                                                       const float* __restrict__ aux0g, const float* __restrict__ qsq,
+                                                       const float* __restrict__ aux0g, const float* __restrict__ qsq, const float* __restrict__ qscl,
                                                        int nq_end) {
     using Shape = MfmaShape<MF>;
     using Acc = typename Shape::Acc;
@@ -120,7 +120,10 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
         thr_l[qt] = 0.f; qinv_l[qt] = 1.f; qsq_l[qt] = 0.f;
         if (q_ok[qt]) {
             if (MODE == 1) thr_l[qt] = a.thr[ql[qt]];
-            if (METRIC == 1) qinv_l[qt] = a.qinv[q];
+            // qscl = 2^-e: the fp16 queries were scaled by 2^e into [2^14, 2^15) (hdb_q16_scaled), undone here for free:
+            // it rides on the per-query multiplier of dot / cosine and on the -2 of the euclidean expansion
+            const float qs = qscl[q];
+            qinv_l[qt] = METRIC == 1 ? a.qinv[q] * qs : qs;
             if (METRIC == 2) qsq_l[qt] = qsq[q];
         }
     }
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
     for (int qt = 0; qt < QT; ++qt) {
         thr_cmp[qt] = INFINITY;
         if (MODE == 1 && q_ok[qt]) {
-            if (METRIC == 1 && !HAS_BIAS) { const float tc = thr_l[qt] / qinv_l[qt]; thr_cmp[qt] = tc - fabsf(tc) * 1e-6f; }
+            if (METRIC != 2 && !HAS_BIAS) { const float tc = thr_l[qt] / qinv_l[qt]; thr_cmp[qt] = tc - fabsf(tc) * 1e-6f; }
             else thr_cmp[qt] = thr_l[qt];
         }
     }
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
                         for (int j = 0; j < 4; ++j) {
                             const float x = tv[rt][4 * g + j];
                             if (x >= thr_cmp && rowg + j < n_rows) {
-                                const float sc = hdb_canon((METRIC == 1 && !HAS_BIAS) ? x * qinv_l : x);
+                                const float sc = hdb_canon((METRIC != 2 && !HAS_BIAS) ? x * qinv_l : x);
                                 // LDS ops in inline asm: hipcc would otherwise drain every in-flight LDS-DMA
                                 // (s_waitcnt vmcnt(0)) before touching LDS it cannot prove disjoint from the ring.
                                 unsigned int pos;
@@ -355,11 +358,11 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
             }
 
             // ---- epilogue, first half: turn the dot products into the values that are stored (MODE 0) or
-            // compared (MODE 1), in place.  Filter mode compares the score itself, except cosine without
-            // bias: dot/||v|| against thr/qinv (one multiply per score).
+            // compared (MODE 1), in place.  Filter mode compares the score itself, except dot / cosine without
+            // bias: the raw dot (dot/||v||) against thr divided by the per-query multiplier.
             const float* ax0 = auxbuf + (st_cur * 2 + 0) * 64;
             const float* ax1 = auxbuf + (st_cur * 2 + 1) * 64;
-            if (METRIC != 0 || HAS_BIAS) {
+            if (METRIC != 0 || HAS_BIAS || MODE == 0) {
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
@@ -376,12 +379,12 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
                             for (int j = 0; j < 4; ++j) {
                                 const float dot = acc[qt][rt][4 * g + j];
                                 float x;
-                                if (METRIC == 0) x = dot + bj[j];
+                                if (METRIC == 0) x = HAS_BIAS ? fmaf(dot, qinv_l[qt], bj[j]) : dot * qinv_l[qt];   // MODE 0 only without bias
                                 else if (METRIC == 1) {
                                     if (MODE == 1 && !HAS_BIAS) x = dot * aj[j];
                                     else x = HAS_BIAS ? fmaf(dot * aj[j], qinv_l[qt], bj[j]) : dot * aj[j] * qinv_l[qt];
                                 } else {
-                                    const float d2 = fmaxf(aj[j] + qsq_l[qt] - 2.f * dot, 0.f);
+                                    const float d2 = fmaxf(fmaf(-2.f * qinv_l[qt], dot, aj[j] + qsq_l[qt]), 0.f);
                                     // v_sqrt_f32 / v_rcp_f32 (1 ulp each): the IEEE expansions of sqrtf and the division
                                     // cost ~25 VALU per score, on every row x query, for a result needed to 1e-3
                                     x = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_sqrtf(d2)) + (HAS_BIAS ? bj[j] : 0.f);
@@ -429,10 +432,18 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
     }
 }
 
-// fp32 -> fp16 queries (round to nearest even, like numpy's astype(float16))
-__global__ void hdb_q_to_f16_kernel(const float* Q, int64_t count, _Float16* out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) out[i] = (_Float16)Q[i];
+// fp32 -> scaled fp16 queries for the matrix pipe (hdb_q16_scale, hdb_common.h); qscl[q] = 1 / scale.  One wave per
+// query.  The prep kernel does the same for plain queries; this one serves the centred copies of pearson.
+__global__ __launch_bounds__(64) void hdb_q_to_f16_kernel(const float* Q, int nq, int d, _Float16* out, float* qscl) {
+    const int q = blockIdx.x;
+    if (q >= nq) return;
+    float amax = 0.f;
+    for (int e = threadIdx.x; e < d; e += 64) amax = fmaxf(amax, fabsf(Q[(int64_t)q * d + e]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    const float scale = hdb_q16_scale(amax);
+    for (int e = threadIdx.x; e < d; e += 64) out[(int64_t)q * d + e] = (_Float16)(Q[(int64_t)q * d + e] * scale);
+    if (threadIdx.x == 0) qscl[q] = 1.f / scale;
 }
 
 // Euclidean scores from the MFMA path come from ||v||^2 + ||q||^2 - 2 v.q, which cancels when v ~ q (an
@@ -467,7 +478,7 @@ static size_t mfma_lds_bytes(int stage_bytes) {
 }
 
 template <int MF, int QT, int D, int R, int MODE, int METRIC, bool HAS_BIAS>
-static int launch_one(const ScanArgs& a, const void* q16, const float* aux0, const float* qsq, int nq_launch, int blocks, hipStream_t st) {
+static int launch_one(const ScanArgs& a, const void* q16, const float* aux0, const float* qsq, const float* qscl, int nq_launch, int blocks, hipStream_t st) {
     auto kern = hdb_mfma_kernel<MF, QT, D, R, MODE, METRIC, HAS_BIAS>;
     const size_t lds = mfma_lds_bytes(R * D * 2);
     static bool attr_done = false;          // per instantiation
@@ -477,26 +488,26 @@ static int launch_one(const ScanArgs& a, const void* q16, const float* aux0, con
         attr_done = true;
     }
     const dim3 grid(blocks, (nq_launch + 8 * MF * QT - 1) / (8 * MF * QT));
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a, (const _Float16*)q16, aux0, qsq, a.q0 + nq_launch);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a, (const _Float16*)q16, aux0, qsq, qscl, a.q0 + nq_launch);
     return (int)hipGetLastError();
 }
 
 template <int MF, int QT, int D, int R, int MODE>
-static int launch_metric(const ScanArgs& a, const void* q16, const float* sqnorm, const float* qsq, int nq_launch, int blocks, hipStream_t st) {
+static int launch_metric(const ScanArgs& a, const void* q16, const float* sqnorm, const float* qsq, const float* qscl, int nq_launch, int blocks, hipStream_t st) {
     const bool b = a.bias != nullptr;
-    if (a.metric == HDB_DOT) return b ? launch_one<MF, QT, D, R, MODE, 0, true>(a, q16, nullptr, qsq, nq_launch, blocks, st)
-                                      : launch_one<MF, QT, D, R, MODE, 0, false>(a, q16, nullptr, qsq, nq_launch, blocks, st);
-    if (a.metric == HDB_COSINE) return b ? launch_one<MF, QT, D, R, MODE, 1, true>(a, q16, a.inv_norm, qsq, nq_launch, blocks, st)
-                                         : launch_one<MF, QT, D, R, MODE, 1, false>(a, q16, a.inv_norm, qsq, nq_launch, blocks, st);
-    if (a.metric == HDB_EUCLIDEAN) return b ? launch_one<MF, QT, D, R, MODE, 2, true>(a, q16, sqnorm, qsq, nq_launch, blocks, st)
-                                            : launch_one<MF, QT, D, R, MODE, 2, false>(a, q16, sqnorm, qsq, nq_launch, blocks, st);
+    if (a.metric == HDB_DOT) return b ? launch_one<MF, QT, D, R, MODE, 0, true>(a, q16, nullptr, qsq, qscl, nq_launch, blocks, st)
+                                      : launch_one<MF, QT, D, R, MODE, 0, false>(a, q16, nullptr, qsq, qscl, nq_launch, blocks, st);
+    if (a.metric == HDB_COSINE) return b ? launch_one<MF, QT, D, R, MODE, 1, true>(a, q16, a.inv_norm, qsq, qscl, nq_launch, blocks, st)
+                                         : launch_one<MF, QT, D, R, MODE, 1, false>(a, q16, a.inv_norm, qsq, qscl, nq_launch, blocks, st);
+    if (a.metric == HDB_EUCLIDEAN) return b ? launch_one<MF, QT, D, R, MODE, 2, true>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st)
+                                            : launch_one<MF, QT, D, R, MODE, 2, false>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
     return (int)hipErrorNotSupported;
 }
 
 template <int MF, int QT, int D, int R>
-static int launch_mode(const ScanArgs& a, int mode, const void* q16, const float* sqnorm, const float* qsq, int nq_launch, int blocks, hipStream_t st) {
-    if (mode == 0) return launch_metric<MF, QT, D, R, 0>(a, q16, sqnorm, qsq, nq_launch, blocks, st);
-    return launch_metric<MF, QT, D, R, 1>(a, q16, sqnorm, qsq, nq_launch, blocks, st);
+static int launch_mode(const ScanArgs& a, int mode, const void* q16, const float* sqnorm, const float* qsq, const float* qscl, int nq_launch, int blocks, hipStream_t st) {
+    if (mode == 0) return launch_metric<MF, QT, D, R, 0>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
+    return launch_metric<MF, QT, D, R, 1>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
 }
 
 // Geometry table: rows per LDS stage (stage = R*d*2 bytes <= 48 KiB, three stages + lists <= 160 KiB).
@@ -526,7 +537,7 @@ extern "C" int hdb_mfma_queries_per_pass(int d, int nq) { return (d == 384 && nq
 
 // a.ntiles / a.tile_stride are in units of hdb_mfma_tile_rows(d) rows here.
 extern "C" int hdb_launch_mfma_scan(const ScanArgs* args, int mode, int nq_launch, const void* q16, const float* sqnorm,
-                                    const float* qsq, int max_blocks, void* stream) {
+                                    const float* qsq, const float* qscl, int max_blocks, void* stream) {
     const ScanArgs& a = *args;
     hipStream_t st = (hipStream_t)stream;
     if (a.mask) return (int)hipErrorNotSupported;
@@ -534,24 +545,23 @@ extern "C" int hdb_launch_mfma_scan(const ScanArgs* args, int mode, int nq_launc
     if (max_blocks > 0 && max_blocks < blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
     switch (a.d) {
-        case 128: return launch_mode<16, 1, 128, 64>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
-        case 256: return launch_mode<16, 1, 256, 64>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
+        case 128: return launch_mode<16, 1, 128, 64>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
+        case 256: return launch_mode<16, 1, 256, 64>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
         case 384:
-            if (nq_launch > 128 && g_mfma_variant == 32) return launch_mode<32, 1, 384, 64>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
-            if (nq_launch > 128) return launch_mode<16, 2, 384, 64>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
-            return launch_mode<16, 1, 384, 64>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
-        case 512: return launch_mode<16, 1, 512, 32>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
-        case 640: return launch_mode<16, 1, 640, 32>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
-        case 768: return launch_mode<16, 1, 768, 32>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
-        case 1024: return launch_mode<16, 1, 1024, 16>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
-        case 1536: return launch_mode<16, 1, 1536, 16>(a, mode, q16, sqnorm, qsq, nq_launch, blocks, st);
+            if (nq_launch > 128 && g_mfma_variant == 32) return launch_mode<32, 1, 384, 64>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
+            if (nq_launch > 128) return launch_mode<16, 2, 384, 64>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
+            return launch_mode<16, 1, 384, 64>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
+        case 512: return launch_mode<16, 1, 512, 32>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
+        case 640: return launch_mode<16, 1, 640, 32>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
+        case 768: return launch_mode<16, 1, 768, 32>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
+        case 1024: return launch_mode<16, 1, 1024, 16>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
+        case 1536: return launch_mode<16, 1, 1536, 16>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
         default: return (int)hipErrorNotSupported;
     }
 }
 
-extern "C" int hdb_launch_q_to_f16(const float* Q, int nq, int d, void* q16, void* stream) {
-    const int64_t count = (int64_t)nq * d;
-    hipLaunchKernelGGL(hdb_q_to_f16_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Q, count, (_Float16*)q16);
+extern "C" int hdb_launch_q_to_f16(const float* Q, int nq, int d, void* q16, float* qscl, void* stream) {
+    hipLaunchKernelGGL(hdb_q_to_f16_kernel, dim3(nq), dim3(64), 0, (hipStream_t)stream, Q, nq, d, (_Float16*)q16, qscl);
     return (int)hipGetLastError();
 }
 

@@ -264,17 +264,26 @@ __global__ __launch_bounds__(256) void hdb_rownorm_kernel(const T* V, int64_t n,
     }
 }
 
-// Per-query prep: qinv = 1/||q|| (0 -> 1), qsq = ||q||^2, NaN flag, and (q16 != nullptr) the fp16 copy of the
-// query that the MFMA scan multiplies with (round to nearest even, like numpy's astype(float16)).  One wave per query.
+// Per-query prep: qinv = 1/||q|| (0 -> 1), qsq = ||q||^2, NaN flag, and (q16 != nullptr) the scaled fp16 copy of
+// the query that the MFMA scan multiplies with, see hdb_q16_scaled.  One wave per query.
 template <typename Acc>
-__global__ __launch_bounds__(64) void hdb_qprep_kernel(const Acc* Q, int nq, int d, float* qinv, float* qsq, int* qnan, _Float16* q16) {
+__global__ __launch_bounds__(64) void hdb_qprep_kernel(const Acc* Q, int nq, int d, float* qinv, float* qsq, int* qnan, _Float16* q16,
+                                                       float* qscl) {
     const int q = blockIdx.x;
     if (q >= nq) return;
     Acc s = Acc(0);
+    float amax = 0.f;
     for (int e = threadIdx.x; e < d; e += 64) {
         const Acc x = Q[(int64_t)q * d + e];
         s += x * x;
-        if (q16) q16[(int64_t)q * d + e] = (_Float16)x;
+        amax = fmaxf(amax, fabsf((float)x));
+    }
+    if (q16) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        const float scale = hdb_q16_scale(amax);
+        for (int e = threadIdx.x; e < d; e += 64) q16[(int64_t)q * d + e] = (_Float16)((float)Q[(int64_t)q * d + e] * scale);
+        if (threadIdx.x == 0) qscl[q] = 1.f / scale;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
@@ -430,10 +439,11 @@ extern "C" int hdb_launch_rownorm(const void* V, int64_t n, int d, int dtype, fl
     return (int)hipGetLastError();
 }
 
-extern "C" int hdb_launch_qprep(const void* Q, int nq, int d, bool f64, float* qinv, float* qsq, int* qnan, void* q16, void* stream) {
+extern "C" int hdb_launch_qprep(const void* Q, int nq, int d, bool f64, float* qinv, float* qsq, int* qnan, void* q16, float* qscl,
+                                void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    if (f64) hipLaunchKernelGGL(hdb_qprep_kernel<double>, dim3(nq), dim3(64), 0, st, (const double*)Q, nq, d, qinv, qsq, qnan, (_Float16*)q16);
-    else hipLaunchKernelGGL(hdb_qprep_kernel<float>, dim3(nq), dim3(64), 0, st, (const float*)Q, nq, d, qinv, qsq, qnan, (_Float16*)q16);
+    if (f64) hipLaunchKernelGGL(hdb_qprep_kernel<double>, dim3(nq), dim3(64), 0, st, (const double*)Q, nq, d, qinv, qsq, qnan, (_Float16*)q16, qscl);
+    else hipLaunchKernelGGL(hdb_qprep_kernel<float>, dim3(nq), dim3(64), 0, st, (const float*)Q, nq, d, qinv, qsq, qnan, (_Float16*)q16, qscl);
     return (int)hipGetLastError();
 }
 

@@ -574,6 +574,37 @@ def test_mfma_shapes_and_euclidean(orc, d, nq, metric, bias):
         ix.close()
 
 
+@pytest.mark.parametrize("metric,scale", [("dot_product", 1e6), ("dot_product", 3e-7), ("dot_product", 8.0),
+                                          ("cosine_similarity", 1e6), ("cosine_similarity", 3e-7), ("cosine_similarity", 8.0),
+                                          ("euclidean_metric", 8.0)])     # |q| >> |v| makes 1/(1+dist) ill-conditioned in fp32
+def test_mfma_query_magnitude(orc, metric, scale):
+    """fp32 queries far outside the fp16 range (or deep in its subnormals) on an fp16 matrix: the MFMA scan multiplies
+    with a power-of-two scaled fp16 copy and must agree with the VALU scan (exact fp32 queries) and the oracle."""
+    from hyperdb._native import GpuIndex, METRIC_IDS
+    rng = np.random.default_rng(77)
+    n, d, k = 40_000, 384, 30
+    V = rng.standard_normal((n, d)).astype(np.float32).astype(np.float16)
+    Q = (rng.standard_normal((5, d)) * scale).astype(np.float32)
+    Q[:, ::7] *= 1e-3                                          # wide dynamic range inside one query
+    mid = METRIC_IDS[metric]
+    ix = GpuIndex(V)
+    try:
+        for sl in (slice(0, 1), slice(0, 5)):                   # single query and a small batch
+            mi, ms, mst = ix.topk_device(Q[sl], k, mid)
+            assert ix.stat("mfma") == 1 and int(mst.abs().sum().item()) == 0
+            ix.set_option("use_mfma", 0)
+            vi, vs, _ = ix.topk_device(Q[sl], k, mid)
+            ix.set_option("use_mfma", 1)
+            assert ix.stat("mfma") == 0
+            mi_h, ms_h, vi_h, vs_h = mi.cpu().numpy(), ms.cpu().numpy(), vi.cpu().numpy(), vs.cpu().numpy()
+            assert np.isfinite(ms_h).all()
+            for qi in range(mi_h.shape[0]):
+                ref = float(np.abs(vs_h[qi]).max()) or 1.0        # compare at unit scale whatever the query magnitude
+                assert orc.same_result_modulo_ties(mi_h[qi], ms_h[qi] / ref, vi_h[qi], vs_h[qi] / ref, 1e-3), (qi, scale)
+    finally:
+        ix.close()
+
+
 @pytest.mark.parametrize("metric,k", [("cosine_similarity", 5000), ("hamming_distance", 3000), ("dot_product", 60_000)])
 def test_large_k_full_sort_path(ranking, orc, metric, k):
     """k above HDB_MAX_K on a matrix larger than the candidate list: all-scores + stable radix sort."""
