@@ -31,7 +31,7 @@ int hdb_launch_thr(const uint32_t* hist, int nq, int npass, uint32_t m, uint32_t
 int hdb_launch_fill_thr(float* thr, uint32_t* cnt, int nq, float v, void* stream);
 void hdb_set_finalize_threads(int t);
 int hdb_launch_sample_thr(const float* scores, int64_t n, int64_t ld, int nq, uint32_t m, float* thr, uint32_t* cnt, void* stream);
-int hdb_launch_collect(const float* scores, int64_t n, int64_t ld, int nq, const uint32_t* hist, uint32_t k, uint32_t* cnt,
+int hdb_launch_collect(const float* scores, int64_t n, int64_t ld, int nq, const uint32_t* hist, int npass, uint32_t k, uint32_t* cnt,
                        unsigned long long* cand, uint32_t cap, uint32_t* tie_info, void* stream);
 int hdb_launch_finalize(const unsigned long long* cand, const uint32_t* cnt, uint32_t cap, int nq, uint32_t k, uint32_t kk,
                         int64_t row_base, int64_t* idx_out, float* score_out, int32_t* status, const int* qnan, void* stream);
@@ -574,10 +574,18 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
             prof_begin(ix, st);
             rc = run_scan(ix, s, 0, cq, qb, mfma, st); if (rc) return rc;
             prof_end(ix, st);
-            HIP_TRY(hipMemsetAsync(hist, 0, (size_t)cq * 4 * HDB_RADIX_BINS * 4, st));
-            HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)cq * 4, st));
-            for (int p = 0; p < 4; ++p) LAUNCH_TRY(hdb_launch_hist(sbuf, n, ld_n, cq, hist, p, kk, st));
-            LAUNCH_TRY(hdb_launch_collect(sbuf, n, ld_n, cq, hist, kk, cnt, cand, HDB_CAND_CAP, tie_info, st));
+            // cnt and hist are neighbours in the workspace: one memset clears both
+            HIP_TRY(hipMemsetAsync(cnt, 0, (size_t)((char*)hist - (char*)cnt) + (size_t)cq * 4 * HDB_RADIX_BINS * 4, st));
+            // hamming scores are integers in [0, d]: their float keys are zero below the top 8 + bits(d) bits, so the
+            // last radix pass (the last two for d < 128) would only re-read the scores to find every key in bin 0
+            int npass = 4;
+            if (metric == HDB_HAMMING && !ix->bias && !ix->mask) {
+                int bits = 0;
+                while ((ix->d >> bits) != 0) ++bits;
+                npass = std::min(4, (8 + bits + 7) / 8);
+            }
+            for (int p = 0; p < npass; ++p) LAUNCH_TRY(hdb_launch_hist(sbuf, n, ld_n, cq, hist, p, kk, st));
+            LAUNCH_TRY(hdb_launch_collect(sbuf, n, ld_n, cq, hist, npass, kk, cnt, cand, HDB_CAND_CAP, tie_info, st));
         }
         if (mfma && metric == HDB_EUCLIDEAN)     // the MFMA path scores through ||v||^2+||q||^2-2v.q: redo near-duplicates directly
             LAUNCH_TRY(hdb_launch_rescore_euclid(cand, cnt, HDB_CAND_CAP, cq, ix->V, ix->d, (const float*)dev_Q, q0, ix->bias, st));

@@ -1,24 +1,26 @@
-// hdb_mfma.hip -- batched Q.V^T scan on the gfx950 matrix cores (fp16 data, fp32 accumulate).
+// hdb_mfma.hip -- the Q.V^T row scan of fp16 matrices on the gfx950 matrix cores (fp32 accumulate), 1..256 queries
+// per pass over V.
 //
 // Replaces "np.dot(vectors, query.T)" (hyperdb/ranking_algorithm.py:29,:41) and, through
-// ||v-q||^2 = ||v||^2 + ||q||^2 - 2 v.q, "np.linalg.norm(vectors - query, axis=1)" (:49) for a batch of
-// queries: the reference takes one query per call; here up to 8*MF queries ride on ONE pass over V.
+// ||v-q||^2 = ||v||^2 + ||q||^2 - 2 v.q, "np.linalg.norm(vectors - query, axis=1)" (:49).  The reference takes one
+// query per call; here up to 8*MF*QT queries ride on ONE pass over V, and a single query takes the same kernel (one
+// wave multiplies, the kernel is then a pure HBM streaming kernel: 6.9-7.1 TB/s at N=10M, d=384).
 //
 // Work decomposition (one workgroup = 8 waves = 512 threads, one workgroup per CU, persistent):
-//   * wave w owns MF queries of the batch (MF = 32: v_mfma_f32_32x32x16_f16, MF = 16:
-//     v_mfma_f32_16x16x32_f16); their fp16 values for ALL k live in its registers as MFMA B fragments
-//     (d/8 VGPRs for MF=16, d/4 for MF=32), loaded once;
+//   * wave w owns MF*QT queries of the batch (MF = 16: v_mfma_f32_16x16x32_f16, QT = 1 or 2 query tiles per wave;
+//     MF = 32: v_mfma_f32_32x32x16_f16, kept for A/B runs); their scaled fp16 values (hdb_q16_scale) for ALL k
+//     live in its registers as MFMA B fragments (QT*d/8 VGPRs for MF=16), loaded once;
 //   * the workgroup streams tiles of R rows of V through a 3-deep LDS ring filled by LDS-DMA
 //     (global_load_lds_dwordx4, 1 KiB per wave-instruction, source-side XOR swizzle so that the
 //     lane-linear LDS image is bank-conflict-free for the ds_read_b128 A-fragment reads), together with
 //     the per-row aux values (1/||v|| or ||v||^2, bias);
-//   * every wave multiplies the whole tile by its queries, one ds_read_b128 per MFMA, issued two k-steps
+//   * every wave multiplies the whole tile by its queries, one ds_read_b128 per QT MFMAs, issued 2-3 k-steps
 //     ahead from inline asm with counted lgkmcnt waits; accumulators never leave registers;
 //   * epilogue in registers: scale / bias / threshold compare behind a group-max prefilter; survivors go
 //     to a small LDS list that is flushed to the per-query candidate lists with global atomics every few
 //     hundred tiles.  The N x Q score matrix is never written (10 GB at N=10M, Q=256).
 // Synchronisation: one raw s_barrier per tile; tile t+2 is in flight while tile t is multiplied (counted
-// s_waitcnt vmcnt, never 0 in the steady state); LDS-DMA pieces are issued between the MFMAs.
+// s_waitcnt vmcnt, never 0 in the steady state).
 // Algorithmic bytes per row: d*2 (V read exactly once per pass); FLOPs: 2*Q*d per row.
 #include "hdb_common.h"
 #include "../../include/hyperdb_hip.h"

@@ -333,35 +333,49 @@ __global__ __launch_bounds__(64) void hdb_qsign_kernel(const Acc* Q, int nq, int
     }
 }
 
-// grid = (blocks, nq); each thread owns 4 consecutive rows.
+// grid = (blocks, ceil(nq / QH)); each thread owns 4 consecutive rows and scores them against QH queries per
+// pass over the bit matrix (a batch re-reads the bits once per QH queries, not once per query).
 // JACCARD: |v & q| / |v | q| on the same sign bits (ranking_algorithm.py:63-75), 0/0 -> NaN like numpy.
-template <int MODE, bool JACCARD>
+template <int MODE, bool JACCARD, int QH>
 __global__ __launch_bounds__(256) void hdb_hamming_kernel(ScanArgs a, const uint32_t* bits, int64_t npad, int W,
                                                           const uint32_t* qbits, int nq_end) {
-    __shared__ uint32_t qb[512];
-    const int q = a.q0 + blockIdx.y;
-    for (int w = threadIdx.x; w < W; w += 256) qb[w] = qbits[(int64_t)q * W + w];
+    __shared__ uint32_t qb[QH][512];
+    const int q0 = a.q0 + blockIdx.y * QH;
+    for (int i = threadIdx.x; i < QH * W; i += 256) {
+        const int qq = i / W, w = i - qq * W;
+        qb[qq][w] = qbits[(int64_t)min(q0 + qq, nq_end - 1) * W + w];
+    }
     __syncthreads();
     const int64_t nquads = (a.n + 3) / 4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nquads; i += (int64_t)gridDim.x * 256) {
-        uint32_t mism[4] = {0, 0, 0, 0}, uni[4] = {0, 0, 0, 0};
+        uint32_t mism[QH][4], uni[QH][4];
+#pragma unroll
+        for (int qq = 0; qq < QH; ++qq)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { mism[qq][u] = 0; uni[qq][u] = 0; }
         for (int w = 0; w < W; ++w) {
             const uint4 v = *reinterpret_cast<const uint4*>(bits + (int64_t)w * npad + 4 * i);
-            const uint32_t qq = qb[w];
-            if (JACCARD) {
-                mism[0] += __popc(v.x & qq); mism[1] += __popc(v.y & qq); mism[2] += __popc(v.z & qq); mism[3] += __popc(v.w & qq);
-                uni[0] += __popc(v.x | qq); uni[1] += __popc(v.y | qq); uni[2] += __popc(v.z | qq); uni[3] += __popc(v.w | qq);
-            } else {
-                mism[0] += __popc(v.x ^ qq); mism[1] += __popc(v.y ^ qq);
-                mism[2] += __popc(v.z ^ qq); mism[3] += __popc(v.w ^ qq);
+            const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int qq = 0; qq < QH; ++qq) {
+                const uint32_t qw = qb[qq][w];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (JACCARD) { mism[qq][u] += __popc(vv[u] & qw); uni[qq][u] += __popc(vv[u] | qw); }
+                    else mism[qq][u] += __popc(vv[u] ^ qw);
+                }
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t row = 4 * i + u;
-            if (row < a.n && q < nq_end) {
-                const float sc = JACCARD ? (float)mism[u] / (float)uni[u] : (float)(a.d - (int)mism[u]);
-                hdb_emit<MODE>(a, q, row, row, sc);
+        for (int qq = 0; qq < QH; ++qq) {
+            const int q = q0 + qq;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t row = 4 * i + u;
+                if (row < a.n && q < nq_end) {
+                    const float sc = JACCARD ? (float)mism[qq][u] / (float)uni[qq][u] : (float)(a.d - (int)mism[qq][u]);
+                    hdb_emit<MODE>(a, q, row, row, sc);
+                }
             }
         }
     }
@@ -467,13 +481,20 @@ extern "C" int hdb_launch_hamming(const ScanArgs* args, int mode, int nq_launch,
                                   int W, const uint32_t* qbits, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const ScanArgs& a = *args;
-    const dim3 grid(hdb_grid_for((a.n + 3) / 4, 256, 2048), nq_launch);
     const int nq_end = a.q0 + nq_launch;
     const bool jac = a.metric == HDB_JACCARD;
-    if (mode == 0) { if (jac) hipLaunchKernelGGL((hdb_hamming_kernel<0, true>), grid, dim3(256), 0, st, a, bits, npad, W, qbits, nq_end);
-                     else hipLaunchKernelGGL((hdb_hamming_kernel<0, false>), grid, dim3(256), 0, st, a, bits, npad, W, qbits, nq_end); }
-    else { if (jac) hipLaunchKernelGGL((hdb_hamming_kernel<1, true>), grid, dim3(256), 0, st, a, bits, npad, W, qbits, nq_end);
-           else hipLaunchKernelGGL((hdb_hamming_kernel<1, false>), grid, dim3(256), 0, st, a, bits, npad, W, qbits, nq_end); }
+    const int blocks = hdb_grid_for((a.n + 3) / 4, 256, 2048);
+#define HDB_HAM_LAUNCH(MODE_, JAC_, QH_)                                                                              \
+    hipLaunchKernelGGL((hdb_hamming_kernel<MODE_, JAC_, QH_>), dim3(blocks, (nq_launch + QH_ - 1) / QH_), dim3(256), 0, st, a, bits, \
+                       npad, W, qbits, nq_end)
+    if (nq_launch == 1) {
+        if (mode == 0) { if (jac) HDB_HAM_LAUNCH(0, true, 1); else HDB_HAM_LAUNCH(0, false, 1); }
+        else { if (jac) HDB_HAM_LAUNCH(1, true, 1); else HDB_HAM_LAUNCH(1, false, 1); }
+    } else {
+        if (mode == 0) { if (jac) HDB_HAM_LAUNCH(0, true, 4); else HDB_HAM_LAUNCH(0, false, 4); }
+        else { if (jac) HDB_HAM_LAUNCH(1, true, 4); else HDB_HAM_LAUNCH(1, false, 4); }
+    }
+#undef HDB_HAM_LAUNCH
     return (int)hipGetLastError();
 }
 

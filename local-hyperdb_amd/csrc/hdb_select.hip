@@ -64,8 +64,10 @@ __device__ Prefix hdb_derive_prefix(const uint32_t* hist_q, int npass, uint32_t 
 
 // ------------------------------------------------------------------------------------------------
 // Histogram pass.  grid = (blocks, nq).  Keys not matching the prefix of earlier passes are skipped.
-// Wave-aggregated LDS atomics: lanes with the same bin elect one adder (score keys cluster in a
-// handful of exponent bins, which would serialise plain atomics).
+// LDS atomics, with ONE round of wave aggregation first: the lanes that share the first active lane's bin
+// elect one adder (in the leading passes nearly all keys of a wave sit in one exponent bin, which would
+// serialise 64 plain atomics), the others add for themselves (a few-way conflict at most; looping the
+// election over every distinct bin cost 144 us per pass on hamming scores, ~30 distinct bins per wave).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void hdb_hist_kernel(const float* scores, int64_t n, int64_t ld, uint32_t* hist,
                                                        int pass, uint32_t k) {
@@ -92,13 +94,14 @@ __global__ __launch_bounds__(256) void hdb_hist_kernel(const float* scores, int6
             active = (key & mask) == prefix;
             bin = (key >> shift) & 255u;
         }
-        unsigned long long todo = __ballot(active);
-        while (todo) {
+        const unsigned long long todo = __ballot(active);
+        if (todo) {
             const int leader = (int)__ffsll((long long)todo) - 1;
             const uint32_t lb = __shfl(bin, leader, 64);
-            const unsigned long long same = __ballot(active && bin == lb);
+            const bool with_leader = active && bin == lb;
+            const unsigned long long same = __ballot(with_leader);
             if (lane == leader) atomicAdd(&lh[lb], (uint32_t)__popcll(same));
-            todo &= ~same;
+            else if (active && !with_leader) atomicAdd(&lh[bin], 1u);
         }
     }
     __syncthreads();
@@ -183,13 +186,14 @@ __global__ void hdb_fill_thr_kernel(float* thr, uint32_t* cnt, int nq, float v) 
 // Exact path: collect keys above the k-th key, and its ties when they fit.
 // tie_info[q] = {kth key, need (ties still wanted), ties_all flag, count_gt}
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void hdb_collect_kernel(const float* scores, int64_t n, int64_t ld, const uint32_t* hist,
+// npass < 4 is for scores whose keys are known to be zero below the bits the passes covered (hamming counts).
+__global__ __launch_bounds__(256) void hdb_collect_kernel(const float* scores, int64_t n, int64_t ld, const uint32_t* hist, int npass,
                                                           uint32_t k, uint32_t* cnt, unsigned long long* cand,
                                                           uint32_t cap, uint32_t* tie_info) {
     __shared__ uint32_t s_key, s_need, s_all;
     const int q = blockIdx.y, lane = threadIdx.x & 63;
     if (threadIdx.x < 64) {
-        const Prefix pf = hdb_derive_prefix(hist + (int64_t)q * 4 * HDB_RADIX_BINS, 4, k, lane);
+        const Prefix pf = hdb_derive_prefix(hist + (int64_t)q * 4 * HDB_RADIX_BINS, npass, k, lane);
         if (lane == 0) {
             const uint32_t count_gt = k - pf.need;
             const uint32_t all = (count_gt + pf.bin_count <= cap) ? 1u : 0u;
@@ -469,10 +473,10 @@ extern "C" int hdb_launch_fill_thr(float* thr, uint32_t* cnt, int nq, float v, v
     hipLaunchKernelGGL(hdb_fill_thr_kernel, dim3((nq + 255) / 256), dim3(256), 0, (hipStream_t)stream, thr, cnt, nq, v);
     return (int)hipGetLastError();
 }
-extern "C" int hdb_launch_collect(const float* scores, int64_t n, int64_t ld, int nq, const uint32_t* hist, uint32_t k,
+extern "C" int hdb_launch_collect(const float* scores, int64_t n, int64_t ld, int nq, const uint32_t* hist, int npass, uint32_t k,
                                   uint32_t* cnt, unsigned long long* cand, uint32_t cap, uint32_t* tie_info, void* stream) {
     const dim3 grid(hdb_grid_for(n, 256 * 8, 1024), nq);
-    hipLaunchKernelGGL(hdb_collect_kernel, grid, dim3(256), 0, (hipStream_t)stream, scores, n, ld, hist, k, cnt, cand, cap, tie_info);
+    hipLaunchKernelGGL(hdb_collect_kernel, grid, dim3(256), 0, (hipStream_t)stream, scores, n, ld, hist, npass, k, cnt, cand, cap, tie_info);
     hipLaunchKernelGGL(hdb_ties_seq_kernel, dim3(nq), dim3(1024), 0, (hipStream_t)stream, scores, n, ld, cnt, cand, cap, tie_info);
     return (int)hipGetLastError();
 }
