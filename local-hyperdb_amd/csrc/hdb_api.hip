@@ -106,6 +106,7 @@ struct hdb_index {
     int64_t mfma_min_q = 1;
     int64_t use_mfma = 1;
     int64_t exact_bytes = (int64_t)1 << 30;
+    int64_t bits_fused = 1;           // hamming / jaccard: try the sampled-threshold path first (exact path when it fails)
     int64_t host_direct = 1;          // hdb_topk_host: kernels write a pinned host record themselves (no D2H copy)
     // stats of the last hdb_topk call
     int64_t st_sample_rows = 0, st_sample_m = 0, st_path = 0, st_chunks = 0, st_mfma = 0;
@@ -273,6 +274,7 @@ extern "C" int hdb_set_option(hdb_index* ix, const char* name, int64_t value) {
     else if (!strcmp(name, "finalize_threads")) hdb_set_finalize_threads((int)value);
     else if (!strcmp(name, "mfma_variant")) hdb_set_mfma_variant((int)value);
     else if (!strcmp(name, "host_direct")) ix->host_direct = value;
+    else if (!strcmp(name, "bits_fused")) ix->bits_fused = value;
     else if (!strcmp(name, "profile")) { ix->profile = value; ix->ev_used = 0; }
     else return fail(HDB_ERR_ARG, std::string("hdb_set_option: unknown option ") + name);
     return HDB_OK;
@@ -408,8 +410,10 @@ extern "C" int hdb_scores(hdb_index* ix, const void* dev_q, int metric, float* d
 // The m-th largest of the sampled scores is exceeded by about T rows of the full matrix (Gamma(m)
 // spread), T >= 8k..16k and <= CAP/2, so both "fewer than k pass" and "more than CAP pass" are
 // < 1e-9 events for exchangeable row orders; either one only costs the exact-path re-run.
-static void sample_plan(const hdb_index* ix, uint32_t kk, int tile_rows, int64_t& tiles, int64_t& stride, uint32_t& m) {
+// coarse: the scores take few distinct values (bit metrics), so the rows at the threshold's own level all survive; aim lower.
+static void sample_plan(const hdb_index* ix, uint32_t kk, int tile_rows, bool coarse, int64_t& tiles, int64_t& stride, uint32_t& m) {
     int64_t T = ix->sample_target > 0 ? ix->sample_target : (kk <= 128 ? 2048 : 4096);
+    if (coarse && ix->sample_target <= 0) T /= 2;
     m = kk <= 128 ? 8u : (kk <= 512 ? 64u : 256u);
     int64_t rows = (int64_t)((double)m * (double)ix->n / (double)T);
     rows = std::max<int64_t>(rows, 16 * (int64_t)m);         // at least 16 m sample rows
@@ -445,7 +449,9 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     const bool small = n <= HDB_CAND_CAP;
     const bool is_ham = is_bits_metric(metric);
     const bool is_pearson = metric == HDB_PEARSON;
-    if (is_ham && !small) exact = true;                      // integer scores: massive ties by construction
+    // bit metrics tie massively by construction; the sampled threshold still works while the rows at and above its
+    // level fit the candidate list (random data: yes), and the status word sends the rest through the exact path
+    if (is_ham && !small && !ix->bits_fused) exact = true;
     if (ix->force_exact && !small) exact = true;
     if (!small && (int64_t)kk * 32 > n) exact = true;        // k is a large share of the rows: a sampled threshold cannot help
     const bool mfma = ix->use_mfma && !is_ham && !small && !ix->mask && nq >= ix->mfma_min_q &&
@@ -454,7 +460,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
 
     // ---- plan the chunking --------------------------------------------------------------------
     int64_t s_tiles = 0, s_stride = 1; uint32_t m = 0;
-    if (!small && !exact) sample_plan(ix, kk, tile_rows, s_tiles, s_stride, m);
+    if (!small && !exact) sample_plan(ix, kk, tile_rows, is_ham, s_tiles, s_stride, m);
     const int64_t s_rows = s_tiles * tile_rows;
     const int64_t ld_s = align_up((size_t)std::max<int64_t>(s_rows, 4), 4);
     const int64_t ld_n = align_up((size_t)n, 4);

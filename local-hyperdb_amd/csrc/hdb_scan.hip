@@ -334,7 +334,8 @@ __global__ __launch_bounds__(64) void hdb_qsign_kernel(const Acc* Q, int nq, int
 }
 
 // grid = (blocks, ceil(nq / QH)); each thread owns 4 consecutive rows and scores them against QH queries per
-// pass over the bit matrix (a batch re-reads the bits once per QH queries, not once per query).
+// pass over the bit matrix (a batch re-reads the bits once per QH queries, not once per query).  Work items are the
+// 4 row-quads of each 16-row tile, so the same strided tile sample as the float scans is available (a.tile_stride).
 // JACCARD: |v & q| / |v | q| on the same sign bits (ranking_algorithm.py:63-75), 0/0 -> NaN like numpy.
 template <int MODE, bool JACCARD, int QH>
 __global__ __launch_bounds__(256) void hdb_hamming_kernel(ScanArgs a, const uint32_t* bits, int64_t npad, int W,
@@ -346,8 +347,10 @@ __global__ __launch_bounds__(256) void hdb_hamming_kernel(ScanArgs a, const uint
         qb[qq][w] = qbits[(int64_t)min(q0 + qq, nq_end - 1) * W + w];
     }
     __syncthreads();
-    const int64_t nquads = (a.n + 3) / 4;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nquads; i += (int64_t)gridDim.x * 256) {
+    const int64_t nitems = a.ntiles * 4;
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < nitems; j += (int64_t)gridDim.x * 256) {
+        const int64_t i = hdb_tile_index(j >> 2, a.tile_stride) * 4 + (j & 3);      // row quad in the matrix
+        if (4 * i >= npad) continue;                                                // ragged last tile of a tiny matrix
         uint32_t mism[QH][4], uni[QH][4];
 #pragma unroll
         for (int qq = 0; qq < QH; ++qq)
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(256) void hdb_hamming_kernel(ScanArgs a, const uint
                 const int64_t row = 4 * i + u;
                 if (row < a.n && q < nq_end) {
                     const float sc = JACCARD ? (float)mism[qq][u] / (float)uni[qq][u] : (float)(a.d - (int)mism[qq][u]);
-                    hdb_emit<MODE>(a, q, row, row, sc);
+                    hdb_emit<MODE>(a, q, row, 4 * j + u, sc);
                 }
             }
         }
@@ -483,7 +486,7 @@ extern "C" int hdb_launch_hamming(const ScanArgs* args, int mode, int nq_launch,
     const ScanArgs& a = *args;
     const int nq_end = a.q0 + nq_launch;
     const bool jac = a.metric == HDB_JACCARD;
-    const int blocks = hdb_grid_for((a.n + 3) / 4, 256, 2048);
+    const int blocks = hdb_grid_for(a.ntiles * 4, 256, 2048);
 #define HDB_HAM_LAUNCH(MODE_, JAC_, QH_)                                                                              \
     hipLaunchKernelGGL((hdb_hamming_kernel<MODE_, JAC_, QH_>), dim3(blocks, (nq_launch + QH_ - 1) / QH_), dim3(256), 0, st, a, bits, \
                        npad, W, qbits, nq_end)

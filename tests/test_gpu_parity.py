@@ -312,7 +312,12 @@ def test_full_size_fused_equals_exact(big_fp16, orc, metric):
 def test_full_size_hamming_exact_properties(big_fp16, orc):
     from hyperdb._native import METRIC_IDS
     ix, V, Q = big_fp16
+    import torch
     idx, sc, st = ix.topk_device(Q[:2], 100, METRIC_IDS["hamming_distance"])
+    assert ix.stat("path") == 1 and int(st.abs().sum().item()) == 0, "random data: the sampled threshold must hold for hamming"
+    ei, es, _ = ix.topk_device(Q[:2], 100, METRIC_IDS["hamming_distance"], exact=True)
+    assert ix.stat("path") == 2
+    assert torch.equal(idx, ei) and torch.equal(sc, es), "sampled-threshold path and exact selection must agree bit for bit"
     idx_h, sc_h = idx.cpu().numpy(), sc.cpu().numpy()
     for qi in range(2):
         rows = V[idx[qi]].cpu().numpy()
@@ -393,6 +398,29 @@ def test_massive_float_ties_and_fallback(ranking, orc):
         assert np.allclose(sc, best, rtol=1e-5)         # top-100 all tie at the best score
         want = np.nonzero(np.isclose(ex, best, rtol=1e-6))[0][:100]
         assert np.array_equal(idx, want), "ties must resolve to the lowest row indices"
+    finally:
+        h.close()
+
+
+@pytest.mark.parametrize("metric", ["hamming_distance", "jaccard_similarity"])
+@pytest.mark.parametrize("d", [8, 16, 40])
+def test_bit_metrics_coarse_levels_fall_back(ranking, orc, metric, d):
+    """Few bits per row: every score level holds far more rows than the candidate list, so the sampled threshold
+    overflows and the call must come back through the exact selection -- same rows and scores as the oracle."""
+    rng = np.random.default_rng(d)
+    n, k = 150_000, 100
+    V = rng.standard_normal((n, d)).astype(np.float32)
+    q = rng.standard_normal(d).astype(np.float32)
+    h = ranking.register_vectors(V)
+    try:
+        idx, sc = ranking.hyperDB_ranking_algorithm_sort(h, q.copy(), top_k=k, metric=metric)
+        oi, osc = orc.rank(V, q.copy(), top_k=k, metric=metric)
+        orc.check_topk(idx, sc, V, q.copy(), metric, k, tol=0.0 if metric == "hamming_distance" else 1e-6)
+        assert np.array_equal(np.sort(sc)[::-1], sc)
+        assert np.allclose(sc, np.asarray(osc, dtype=np.float64), rtol=0, atol=0 if metric == "hamming_distance" else 1e-6)
+        for s in np.unique(sc):                                  # the build's tie rule: equal scores by ascending row
+            run = idx[sc == s]
+            assert np.all(np.diff(run) > 0)
     finally:
         h.close()
 
