@@ -153,7 +153,15 @@ int hdb_merge_topk_packed(const void* dev_gathered, int32_t parts, int32_t nq, i
  * "top_k > N returns all rows sorted", ranking_algorithm.py:195-200).  hdb_merge_topk* need parts*k <= 8192. */
 #define HDB_MAX_K 2048
 
-/* Tuning knobs / introspection (bench and tests): name -> value, returns HDB_ERR_ARG if unknown. */
+/* Tuning knobs / introspection (bench and tests): name -> value, returns HDB_ERR_ARG if unknown.
+ * Options:  max_blocks (0 = automatic grid of the row scans), force_exact (1: always the exact selection),
+ *   sample_target (expected survivors of the sampled threshold, 0 = automatic), use_mfma (0: VALU scans only),
+ *   mfma_min_q (smallest batch that takes the MFMA scan on fp16 matrices, default 1), mfma_variant (16 | 32: MFMA
+ *   shape of the 256-query pass), bits_fused (0: hamming / jaccard always through the exact selection),
+ *   host_direct (0: hdb_topk_host always copies through a device record), exact_bytes (score workspace cap of
+ *   the exact path), finalize_threads (256 | 512 | 1024), profile (1: HIP events around the pass over V).
+ * Stats:    path (0 small, 1 sampled threshold, 2 exact, 3 full sort), mfma, chunks, sample_rows, sample_m,
+ *   scan_launches, scan_time_ns (sum over the profiled launches), cand_cap, n, ws_bytes. */
 int hdb_set_option(hdb_index* ix, const char* name, int64_t value);
 int hdb_get_stat(hdb_index* ix, const char* name, int64_t* value);
 
