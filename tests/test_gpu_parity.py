@@ -680,6 +680,30 @@ def test_candidate_cap_boundary(ranking, orc, n):
         h.close()
 
 
+@pytest.mark.parametrize("d", [384, 1536])
+@pytest.mark.parametrize("n", [8193, 8256, 8257, 12345])
+def test_mfma_single_query_small_matrices(orc, d, n):
+    """fp16 matrices just above the small-matrix limit go through the MFMA scan even for one query: ragged last
+    tiles (16- and 64-row geometries), tile counts below the grid size, sample tiles = all tiles."""
+    from hyperdb._native import GpuIndex, METRIC_IDS
+    rng = np.random.default_rng(n + d)
+    V = rng.standard_normal((n, d)).astype(np.float32).astype(np.float16)
+    Q = rng.standard_normal((3, d)).astype(np.float16)
+    ix = GpuIndex(V)
+    try:
+        for metric in ("cosine_similarity", "euclidean_metric"):
+            mid = METRIC_IDS[metric]
+            for sl, k in ((slice(0, 1), 10), (slice(0, 3), 100)):
+                idx, sc = ix.topk(Q[sl], k, mid)
+                assert ix.stat("mfma") == 1
+                for qi in range(idx.shape[0]):
+                    orc.check_topk(idx[qi], sc[qi], V, Q[sl][qi], metric, k, tol=1e-3)
+        idx, sc = ix.topk(V[n - 1:n], 5, METRIC_IDS["cosine_similarity"])     # the very last (ragged-tile) row finds itself
+        assert idx[0][0] == n - 1 and abs(sc[0][0] - 1.0) < 1e-3
+    finally:
+        ix.close()
+
+
 @pytest.mark.parametrize("target", [16, 200_000])
 def test_forced_threshold_failure_falls_back_to_exact(orc, target):
     """sample_target=16 makes the threshold far too high (fewer than k survivors -> UNDERFLOW),
