@@ -160,7 +160,7 @@ int hdb_merge_topk_packed(const void* dev_gathered, int32_t parts, int32_t nq, i
  *   shape of the 256-query pass), bits_fused (0: hamming / jaccard always through the exact selection),
  *   host_direct (0: hdb_topk_host always copies through a device record), exact_bytes (score workspace cap of
  *   the exact path), finalize_threads (256 | 512 | 1024), profile (1: HIP events around the pass over V).
- * Stats:    path (0 small, 1 sampled threshold, 2 exact, 3 full sort), mfma, chunks, sample_rows, sample_m,
+ * Stats:    path (0 small, 1 sampled threshold, 2 exact, 3 full sort), mfma, host_direct, chunks, sample_rows, sample_m,
  *   scan_launches, scan_time_ns (sum over the profiled launches), cand_cap, n, ws_bytes. */
 int hdb_set_option(hdb_index* ix, const char* name, int64_t value);
 int hdb_get_stat(hdb_index* ix, const char* name, int64_t* value);

@@ -109,7 +109,7 @@ struct hdb_index {
     int64_t bits_fused = 1;           // hamming / jaccard: try the sampled-threshold path first (exact path when it fails)
     int64_t host_direct = 1;          // hdb_topk_host: kernels write a pinned host record themselves (no D2H copy)
     // stats of the last hdb_topk call
-    int64_t st_sample_rows = 0, st_sample_m = 0, st_path = 0, st_chunks = 0, st_mfma = 0;
+    int64_t st_sample_rows = 0, st_sample_m = 0, st_path = 0, st_chunks = 0, st_mfma = 0, st_host_direct = 0;
     // optional HIP-event timing of the dominant kernel (the pass over all of V)
     int64_t profile = 0;
     std::vector<hipEvent_t> ev_pool;      // pairs: [2i] start, [2i+1] stop
@@ -287,6 +287,7 @@ extern "C" int hdb_get_stat(hdb_index* ix, const char* name, int64_t* value) {
     else if (!strcmp(name, "path")) *value = ix->st_path;
     else if (!strcmp(name, "chunks")) *value = ix->st_chunks;
     else if (!strcmp(name, "mfma")) *value = ix->st_mfma;
+    else if (!strcmp(name, "host_direct")) *value = ix->st_host_direct;
     else if (!strcmp(name, "cand_cap")) *value = HDB_CAND_CAP;
     else if (!strcmp(name, "n")) *value = ix->n;
     else if (!strcmp(name, "ws_bytes")) *value = (int64_t)ix->ws_bytes;
@@ -623,6 +624,7 @@ extern "C" int hdb_topk_host(hdb_index* ix, const void* dev_Q, int32_t nq, int32
         if (hipPointerGetAttributes(&attr, host_record) == hipSuccess) direct = attr.type == hipMemoryTypeHost && attr.devicePointer == host_record;
         else (void)hipGetLastError();
     }
+    ix->st_host_direct = direct ? 1 : 0;
     char* rec = static_cast<char*>(host_record);
     if (!direct) {
         if (bytes > ix->rec_bytes) {

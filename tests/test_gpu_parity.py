@@ -680,6 +680,35 @@ def test_candidate_cap_boundary(ranking, orc, n):
         h.close()
 
 
+def test_topk_host_pinned_and_pageable_records(orc):
+    """hdb_topk_host stores into pinned records from the kernels themselves and copies for pageable ones; same bytes."""
+    import ctypes, torch
+    from hyperdb import _native
+    from hyperdb._native import GpuIndex, METRIC_IDS
+    rng = np.random.default_rng(3)
+    V = rng.standard_normal((50_000, 128)).astype(np.float32)
+    Q = rng.standard_normal((4, 128)).astype(np.float32)
+    ix = GpuIndex(V)
+    try:
+        k, mid = 20, METRIC_IDS["cosine_similarity"]
+        i1, s1, st1 = ix.topk_views(Q, k, mid)
+        assert ix.stat("host_direct") == 1
+        i1, s1 = i1.copy(), s1.copy()
+        nb = _native.packed_bytes(4, k)
+        page = np.zeros(nb, dtype=np.uint8)                       # ordinary pageable memory
+        qt = torch.from_numpy(Q).cuda()
+        rc = _native._lib.hdb_topk_host(ix._h, ctypes.c_void_p(qt.data_ptr()), 4, k, mid, ctypes.c_void_p(page.ctypes.data),
+                                        _native._stream_ptr(ix.device))
+        assert rc == 0 and ix.stat("host_direct") == 0
+        i2 = page[:4 * k * 8].view(np.int64).reshape(4, k)
+        s2 = page[4 * k * 8:4 * k * 12].view(np.float32).reshape(4, k)
+        assert np.array_equal(i1, i2) and np.array_equal(s1, s2)
+        for qi in range(4):
+            orc.check_topk(i1[qi], s1[qi], V, Q[qi], "cosine_similarity", k, tol=1e-5)
+    finally:
+        ix.close()
+
+
 @pytest.mark.parametrize("d", [384, 1536])
 @pytest.mark.parametrize("n", [8193, 8256, 8257, 12345])
 def test_mfma_single_query_small_matrices(orc, d, n):
