@@ -118,7 +118,11 @@ int hdb_scores(hdb_index* ix, const void* dev_q, int metric, float* dev_out, voi
  * matrices).  Outputs: dev_idx [nq][k] int64 (row_base added; -1 where fewer than k rows exist),
  * dev_score [nq][k] float32, sorted by (score descending, index ascending).
  * dev_status [nq] int32 receives hdb_query_status bits; queries with a non-zero status must be
- * re-run with hdb_topk_exact (the threshold estimate from the row sample failed for them). */
+ * re-run with hdb_topk_exact (the threshold estimate from the row sample failed for them).
+ * On fp16 matrices (d in {128,256,384,512,640,768,1024,1536}; dot, cosine, euclidean, pearson; no row mask) the
+ * scores come from the matrix cores with fp16 copies of the queries (scaled per query by a power of two, so any
+ * float32 magnitude is safe): identical to the reference when the query has the matrix's dtype, within 1e-4
+ * relative for a float32 query.  hdb_set_option(ix, "use_mfma", 0) keeps float32 queries exact (VALU scan). */
 int hdb_topk(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, int metric,
              int64_t* dev_idx, float* dev_score, int32_t* dev_status, void* stream);
 

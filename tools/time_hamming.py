@@ -1,4 +1,4 @@
-"""Latency of the bit-metric path (hamming / jaccard: always the exact selection) at N=10M, d=384."""
+"""Latency of the bit-metric path (hamming / jaccard) at N=10M, d=384: sampled threshold first, exact selection on overflow."""
 import sys, time
 sys.path.insert(0, 'local-hyperdb_amd'); sys.path.insert(0, '.')
 import numpy as np, torch
