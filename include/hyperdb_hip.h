@@ -121,8 +121,9 @@ int hdb_scores(hdb_index* ix, const void* dev_q, int metric, float* dev_out, voi
  * re-run with hdb_topk_exact (the threshold estimate from the row sample failed for them).
  * On fp16 matrices (d in {128,256,384,512,640,768,1024,1536}; dot, cosine, euclidean, pearson; no row mask) the
  * scores come from the matrix cores with fp16 copies of the queries (scaled per query by a power of two, so any
- * float32 magnitude is safe): identical to the reference when the query has the matrix's dtype, within 1e-4
- * relative for a float32 query.  hdb_set_option(ix, "use_mfma", 0) keeps float32 queries exact (VALU scan). */
+ * float32 magnitude is safe) and float32 accumulation: nothing is lost when the query has the matrix's dtype, a
+ * float32 query is rounded to 11 significant bits per element (score error ~1e-4 relative, inside the 1e-3
+ * contract for fp16 data).  hdb_set_option(ix, "use_mfma", 0) keeps float32 queries unrounded (VALU scan). */
 int hdb_topk(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, int metric,
              int64_t* dev_idx, float* dev_score, int32_t* dev_status, void* stream);
 
