@@ -32,6 +32,10 @@ for p in (ROOT, os.path.join(ROOT, "local-hyperdb_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# dmabuf IPC for RCCL / cross-process GPU buffers on this driver; read when the HIP runtime initialises, so set it
+# before torch is imported (it is normally exported already)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 
@@ -166,7 +170,6 @@ def main():
     if world > 1 or os.environ.get("HDB_FORCE_DIST") == "1":     # HDB_FORCE_DIST: exercise the RCCL path on one GPU
         import torch.distributed as dist_mod
         dist = dist_mod
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)
 
     from hyperdb._native import GpuIndex, METRIC_IDS
