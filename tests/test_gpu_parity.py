@@ -680,6 +680,44 @@ def test_candidate_cap_boundary(ranking, orc, n):
         h.close()
 
 
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_fuzz_sampled_threshold_equals_exact_selection(seed):
+    """Random shapes through both selection paths of the same kernels: the sampled-threshold path (status 0) must
+    return exactly the rows and scores of the exact selection -- fp16 MFMA geometries (all d, 1..300 queries, ragged
+    tiles, bias) and the VALU scan (fp32, other d, manhattan)."""
+    import torch
+    from hyperdb._native import GpuIndex, METRIC_IDS
+    rng = np.random.default_rng(seed)
+    mfma_d = [128, 256, 384, 512, 640, 768, 1024, 1536]
+    for case in range(10):
+        use16 = rng.random() < 0.7
+        d = int(rng.choice(mfma_d)) if use16 else int(rng.choice([24, 100, 384, 200]))
+        n = int(rng.integers(8200, 120_000))
+        nq = int(rng.choice([1, 2, 5, 16, 17, 64, 129, 200, 257, 300])) if use16 else int(rng.choice([1, 3, 6]))
+        k = int(rng.choice([1, 7, 100, 257]))
+        metric = str(rng.choice(["dot_product", "cosine_similarity", "euclidean_metric"] + ([] if use16 else ["manhattan_distance"])))
+        V = torch.randn((n, d), generator=torch.Generator().manual_seed(seed * 100 + case))
+        V = V.to(torch.float16 if use16 else torch.float32).cuda()
+        Q = torch.randn((nq, d), generator=torch.Generator().manual_seed(seed * 100 + case + 50)).to(V.dtype).float().cuda()
+        ix = GpuIndex(V)
+        try:
+            if rng.random() < 0.4:
+                ix.set_bias((torch.rand(n, generator=torch.Generator().manual_seed(case)) * 0.3).float().cuda())
+            mid = METRIC_IDS[metric]
+            fi, fs, fst = ix.topk_device(Q, k, mid)
+            path = ix.stat("path")
+            ei, es, _ = ix.topk_device(Q, k, mid, exact=True)
+            ok = (fst == 0)
+            assert bool(ok.all()) or path == 2, (seed, case, "status", fst.cpu().tolist())
+            tag = (seed, case, n, d, nq, k, metric, use16)
+            assert torch.equal(fi[ok], ei[ok]), tag
+            assert torch.equal(fs[ok], es[ok]), tag
+        finally:
+            ix.close()
+        del V, Q
+    torch.cuda.empty_cache()
+
+
 def test_topk_host_pinned_and_pageable_records(orc):
     """hdb_topk_host stores into pinned records from the kernels themselves and copies for pageable ones; same bytes."""
     import ctypes, torch
