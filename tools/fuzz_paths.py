@@ -1,0 +1,42 @@
+"""Long fuzz run: sampled-threshold path vs exact selection on random shapes (see tests/test_gpu_parity.py)."""
+import sys, time
+sys.path.insert(0, 'local-hyperdb_amd'); sys.path.insert(0, '.')
+import numpy as np, torch
+from hyperdb._native import GpuIndex, METRIC_IDS
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+mfma_d = [128, 256, 384, 512, 640, 768, 1024, 1536]
+bad = fallbacks = 0
+t0 = time.time()
+for case in range(cases):
+    use16 = rng.random() < 0.75
+    d = int(rng.choice(mfma_d)) if use16 else int(rng.choice([24, 100, 384, 200, 48]))
+    n = int(rng.integers(8200, 400_000))
+    nq = int(rng.choice([1, 2, 5, 16, 17, 64, 128, 129, 200, 256, 257, 300])) if use16 else int(rng.choice([1, 3, 4, 6]))
+    k = int(rng.choice([1, 7, 100, 128, 257, 1000]))
+    names = ["dot_product", "cosine_similarity", "euclidean_metric", "pearson_correlation", "hamming_distance", "jaccard_similarity"]
+    if not use16: names.append("manhattan_distance")
+    metric = str(rng.choice(names))
+    g = torch.Generator(device='cuda').manual_seed(seed * 100000 + case)
+    V = torch.randn((n, d), generator=g, device='cuda').to(torch.float16 if use16 else torch.float32)
+    if rng.random() < 0.15: V[torch.from_numpy(rng.integers(1, n, size=50)).cuda()] = V[0].clone()   # some duplicate rows
+    Q = torch.randn((nq, d), generator=g, device='cuda').to(V.dtype).float()
+    ix = GpuIndex(V)
+    if rng.random() < 0.4: ix.set_bias((torch.rand(n, generator=g, device='cuda') * 0.3).float())
+    mid = METRIC_IDS[metric]
+    fi, fs, fst = ix.topk_device(Q, k, mid)
+    path = ix.stat("path")
+    ei, es, _ = ix.topk_device(Q, k, mid, exact=True)
+    ok = (fst == 0)
+    fallbacks += int((~ok).sum())
+    same = torch.equal(fi[ok], ei[ok]) and (torch.equal(fs[ok], es[ok]) or torch.equal(torch.nan_to_num(fs[ok], neginf=-1e30), torch.nan_to_num(es[ok], neginf=-1e30)))
+    if not same:
+        bad += 1
+        print("MISMATCH", dict(case=case, n=n, d=d, nq=nq, k=k, metric=metric, fp16=use16, path=path), flush=True)
+    ix.close(); del V, Q
+    if case % 50 == 49:
+        print(f"{case + 1} cases, {bad} mismatches, {fallbacks} queries fell back, {time.time() - t0:.0f} s", flush=True)
+print(f"done: {cases} cases, {bad} mismatches, {fallbacks} fallbacks")
+sys.exit(1 if bad else 0)
