@@ -285,9 +285,9 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps, "p50_latency_ms": 1e3 * float(np.median(lat)),
             "p99_latency_ms": 1e3 * float(np.percentile(lat, 99)),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32" if args.dtype == "fp32" else "f16 data, f32 accumulate", "data": "synthetic",
+            "dtype": "f32" if args.dtype == "fp32" else "f16", "data": "synthetic",
             "config": {"workload": f"N={args.n} d={args.d} {args.dtype} Q=1 {args.metric} top-{args.k}, row-sharded x{world}",
-                       "rows_per_gpu": hi - lo, "exchange": "none" if world == 1 else "1 RCCL all-gather of packed top-k per query"},
+                       "rows_per_gpu": hi - lo, "accumulate": "f32", "exchange": "none" if world == 1 else "1 RCCL all-gather of packed top-k per query"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": headline_kernel, "kernel_us": kern_s * 1e6,
