@@ -436,9 +436,11 @@ extern "C" int hdb_launch_scan(const ScanArgs* args, int dtype, int mode, int nq
     a.nchunks = a.row_bytes / 16;
     const bool vec = (a.row_bytes % 16 == 0) && ((reinterpret_cast<uintptr_t>(a.V) & 15) == 0) &&
                      ((size_t)a.d * (elem == 8 ? 8 : 4) <= 60 * 1024);
-    // grid: with every wave keeping a whole tile (12-24 KiB) in flight, 2 workgroups (8 waves) per CU is the
-    // measured optimum for the non-temporal row stream (6.8 TB/s at 768-byte rows, 6.2-6.5 at 1536)
-    const int auto_blocks = 512;
+    // grid: every wave keeps a whole tile in flight.  With 12 KiB tiles (768-byte rows) 2 workgroups (8 waves) per CU
+    // is the measured optimum (6.8 TB/s); with the 24 KiB tiles of the unrolled 1536-byte-row variant one workgroup
+    // per CU is (N=1M fp32 d=384: 237 vs 246 us; N=10M: 7.02 vs 6.78 TB/s) -- the same ~100 KiB in flight per CU
+    const bool wide_rows = vec && a.row_bytes == 6 * 256 && nq_launch < 3;
+    const int auto_blocks = wide_rows ? 256 : 512;
     const int blocks = hdb_grid_for(a.ntiles, 4, max_blocks > 0 ? max_blocks : auto_blocks);
     if (dtype == HDB_F16) { if (mode == 0) launch_scan_t<__half, 0>(a, nq_launch, blocks, vec, st); else launch_scan_t<__half, 1>(a, nq_launch, blocks, vec, st); }
     else if (dtype == HDB_F32) { if (mode == 0) launch_scan_t<float, 0>(a, nq_launch, blocks, vec, st); else launch_scan_t<float, 1>(a, nq_launch, blocks, vec, st); }
