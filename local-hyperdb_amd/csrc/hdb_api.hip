@@ -41,6 +41,7 @@ int hdb_launch_merge(const void* idx_base, int64_t idx_stride, const void* score
 int hdb_launch_rowstats(const void* V, int64_t n, int d, int dtype, float* pscale, void* stream);
 int hdb_launch_qcentre(const void* Q, int nq, int d, bool f64, void* Qc, float* qscale, void* stream);
 int hdb_launch_recency(const double* ts, int64_t n, double rb, double ts_max, float* out, void* stream);
+int hdb_launch_maskbias(const uint8_t* mask, const float* bias, int64_t n, float* out, void* stream);
 int hdb_mfma_supported(int dtype, int d, int metric);
 int hdb_mfma_tile_rows(int d);
 void hdb_set_mfma_variant(int v);
@@ -93,6 +94,9 @@ struct hdb_index {
     // borrowed
     const float* bias = nullptr;
     const uint8_t* mask = nullptr;
+    // mask folded into a bias vector for the MFMA scan (owned, rebuilt per call: the mask and bias are borrowed)
+    float* mbias = nullptr;
+    int64_t mbias_rows = 0;
     // device copy of the result record of hdb_topk_host (owned)
     char* rec = nullptr;
     size_t rec_bytes = 0;
@@ -235,6 +239,7 @@ extern "C" void hdb_index_destroy(hdb_index* ix) {
     if (ix->nan_flag) (void)hipFree(ix->nan_flag);
     if (ix->bits) (void)hipFree(ix->bits);
     if (ix->pscale) (void)hipFree(ix->pscale);
+    if (ix->mbias) (void)hipFree(ix->mbias);
     if (ix->ws) (void)hipFree(ix->ws);
     if (ix->rec) (void)hipFree(ix->rec);
     for (hipEvent_t e : ix->ev_pool) (void)hipEventDestroy(e);
@@ -455,7 +460,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     if (is_ham && !small && !ix->bits_fused) exact = true;
     if (ix->force_exact && !small) exact = true;
     if (!small && (int64_t)kk * 32 > n) exact = true;        // k is a large share of the rows: a sampled threshold cannot help
-    const bool mfma = ix->use_mfma && !is_ham && !small && !ix->mask && nq >= ix->mfma_min_q &&
+    const bool mfma = ix->use_mfma && !is_ham && !small && nq >= ix->mfma_min_q &&
                       hdb_mfma_supported(ix->dtype, ix->d, is_pearson ? (int)HDB_COSINE : metric);
     const int tile_rows = mfma ? hdb_mfma_tile_rows(ix->d) : 16;
 
@@ -539,6 +544,19 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
         if (dev_status) HIP_TRY(hipMemsetAsync(dev_status, 0, (size_t)nq * sizeof(int32_t), st));
         return HDB_OK;
     }
+    // the MFMA scan has no mask input: excluded rows get a bias of -inf instead (never appended, like the VALU scan)
+    const float* bias_eff = ix->bias;
+    const uint8_t* mask_eff = ix->mask;
+    if (mfma && ix->mask) {
+        if (n > ix->mbias_rows) {
+            if (ix->mbias) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(ix->mbias)); ix->mbias = nullptr; }
+            const int64_t rows = n + n / 4 + 64;
+            HIP_TRY(hipMalloc((void**)&ix->mbias, rows * sizeof(float)));
+            ix->mbias_rows = rows;
+        }
+        LAUNCH_TRY(hdb_launch_maskbias(ix->mask, ix->bias, n, ix->mbias, st));
+        bias_eff = ix->mbias; mask_eff = nullptr;
+    }
     bool q16_ready = q16_in_prep;
     ix->st_sample_rows = s_rows; ix->st_sample_m = m; ix->st_chunks = 0;
     ix->st_path = small ? 0 : (exact ? 2 : 1);
@@ -551,7 +569,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
         QueryBufs qb{qinv, qsq, qbits, q16, qscl};
         ScanArgs a; base_args(ix, a, Qeff, metric_eff);
         if (is_pearson) a.inv_norm = ix->pscale;
-        a.q0 = q0; a.bias = ix->bias;
+        a.q0 = q0; a.bias = bias_eff; a.mask = mask_eff;
         a.thr = thr; a.cnt = cnt; a.cand = cand;
         a.ntiles = (n + tile_rows - 1) / tile_rows;
 

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const _Float1
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float x = tv[rt][4 * g + j];
-                            if (x >= thr_cmp && rowg + j < n_rows) {
+                            if (x >= thr_cmp && rowg + j < n_rows && !(HAS_BIAS && x == -INFINITY)) {   // bias -inf = masked row
                                 const float sc = hdb_canon((METRIC != 2 && !HAS_BIAS) ? x * qinv_l : x);
                                 // LDS ops in inline asm: hipcc would otherwise drain every in-flight LDS-DMA
                                 // (s_waitcnt vmcnt(0)) before touching LDS it cannot prove disjoint from the ring.

@@ -503,6 +503,16 @@ extern "C" int hdb_launch_hamming(const ScanArgs* args, int mode, int nq_launch,
     return (int)hipGetLastError();
 }
 
+// Row mask folded into a bias vector for the MFMA scan (which has no mask input): out = mask ? bias : -inf.
+__global__ __launch_bounds__(256) void hdb_maskbias_kernel(const uint8_t* mask, const float* bias, int64_t n, float* out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = mask[i] ? (bias ? bias[i] : 0.f) : -INFINITY;
+}
+extern "C" int hdb_launch_maskbias(const uint8_t* mask, const float* bias, int64_t n, float* out, void* stream) {
+    hipLaunchKernelGGL(hdb_maskbias_kernel, dim3(hdb_grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, mask, bias, n, out);
+    return (int)hipGetLastError();
+}
+
 // Recency term of hyperDB_ranking_algorithm_sort (ranking_algorithm.py:180-183):
 // bias[i] = recency_bias * exp(ts[i] - max(ts)), difference and exp in float64 (unix-second
 // timestamps lose ~100 s of resolution in float32), result stored as float32.

@@ -718,6 +718,47 @@ def test_fuzz_sampled_threshold_equals_exact_selection(seed):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("keep", [0.5, 0.02, 0.0004])
+def test_row_mask_mfma_equals_valu(orc, keep):
+    """Row masks (filters) on fp16 matrices: the MFMA scan sees them as a bias of -inf and must return what the VALU
+    scan (mask input) returns -- single query and batch, with and without a recency bias, down to fewer than k rows."""
+    import torch
+    from hyperdb._native import GpuIndex, METRIC_IDS
+    rng = np.random.default_rng(int(keep * 1e6))
+    n, d, k = 70_000, 256, 40
+    V = rng.standard_normal((n, d)).astype(np.float32).astype(np.float16)
+    Q = rng.standard_normal((9, d)).astype(np.float16)
+    mask_h = (rng.random(n) < keep).astype(np.uint8)
+    mask_h[:3] = 1
+    mask = torch.from_numpy(mask_h).cuda()
+    bias = torch.from_numpy((rng.random(n) * 0.2).astype(np.float32)).cuda()
+    ix = GpuIndex(V)
+    try:
+        ix.set_row_mask(mask)
+        for use_bias in (False, True):
+            ix.set_bias(bias if use_bias else None)
+            for metric in ("cosine_similarity", "euclidean_metric"):
+                mid = METRIC_IDS[metric]
+                for sl in (slice(0, 1), slice(0, 9)):
+                    mi, ms = ix.topk(Q[sl], k, mid)
+                    assert ix.stat("mfma") == 1
+                    ix.set_option("use_mfma", 0)
+                    vi, vs = ix.topk(Q[sl], k, mid)
+                    ix.set_option("use_mfma", 1)
+                    assert ix.stat("mfma") == 0
+                    for qi in range(mi.shape[0]):
+                        live = mi[qi] >= 0
+                        assert np.array_equal(live, vi[qi] >= 0)
+                        got = mi[qi][live & np.isfinite(ms[qi])]
+                        assert mask_h[got].all(), "an excluded row came back with a finite score"
+                        assert orc.same_result_modulo_ties(mi[qi], np.nan_to_num(ms[qi], neginf=-1e30), vi[qi],
+                                                           np.nan_to_num(vs[qi], neginf=-1e30), 2e-5), (keep, use_bias, metric, qi)
+                        if mask_h.sum() >= k:
+                            assert np.isfinite(ms[qi]).all() and mask_h[mi[qi]].all()
+    finally:
+        ix.close()
+
+
 def test_topk_host_pinned_and_pageable_records(orc):
     """hdb_topk_host stores into pinned records from the kernels themselves and copies for pageable ones; same bytes."""
     import ctypes, torch

@@ -25,6 +25,7 @@ for case in range(cases):
     Q = torch.randn((nq, d), generator=g, device='cuda').to(V.dtype).float()
     ix = GpuIndex(V)
     if rng.random() < 0.4: ix.set_bias((torch.rand(n, generator=g, device='cuda') * 0.3).float())
+    if rng.random() < 0.25: ix.set_row_mask((torch.rand(n, generator=g, device='cuda') < float(rng.choice([0.5, 0.05]))).to(torch.uint8))
     mid = METRIC_IDS[metric]
     fi, fs, fst = ix.topk_device(Q, k, mid)
     path = ix.stat("path")
