@@ -123,7 +123,8 @@ int hdb_scores(hdb_index* ix, const void* dev_q, int metric, float* dev_out, voi
  * scores come from the matrix cores with fp16 copies of the queries (scaled per query by a power of two, so any
  * float32 magnitude is safe) and float32 accumulation: nothing is lost when the query has the matrix's dtype, a
  * float32 query is rounded to 11 significant bits per element (score error ~1e-4 relative, inside the 1e-3
- * contract for fp16 data).  hdb_set_option(ix, "use_mfma", 0) keeps float32 queries unrounded (VALU scan). */
+ * contract for fp16 data).  hdb_set_option(ix, "use_mfma", 0) keeps float32 queries unrounded (VALU scan).
+ * float32 matrices (d in {128,256,384,512,768}) take batches of 5+ queries through fp32 MFMAs: exact fp32 products. */
 int hdb_topk(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, int metric,
              int64_t* dev_idx, float* dev_score, int32_t* dev_status, void* stream);
 

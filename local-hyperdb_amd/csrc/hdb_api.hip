@@ -43,15 +43,15 @@ int hdb_launch_qcentre(const void* Q, int nq, int d, bool f64, void* Qc, float* 
 int hdb_launch_recency(const double* ts, int64_t n, double rb, double ts_max, float* out, void* stream);
 int hdb_launch_maskbias(const uint8_t* mask, const float* bias, int64_t n, float* out, void* stream);
 int hdb_mfma_supported(int dtype, int d, int metric);
-int hdb_mfma_tile_rows(int d);
+int hdb_mfma_tile_rows(int dtype, int d);
 void hdb_set_mfma_variant(int v);
-int hdb_launch_mfma_scan(const ScanArgs* args, int mode, int nq_launch, const void* q16, const float* sqnorm,
+int hdb_launch_mfma_scan(const ScanArgs* args, int dtype, int mode, int nq_launch, const void* q16, const float* sqnorm,
                          const float* qsq, const float* qscl, int max_blocks, void* stream);
 int hdb_launch_q_to_f16(const float* Q, int nq, int d, void* q16, float* qscl, void* stream);
 int hdb_sort_temp_bytes(int64_t n, size_t* bytes);
 int hdb_launch_full_sort(const float* scores, int64_t n, int64_t k, int64_t row_base, uint32_t* work, void* temp, size_t temp_bytes,
                          int64_t* idx_out, float* score_out, void* stream);
-int hdb_launch_rescore_euclid(unsigned long long* cand, const uint32_t* cnt, uint32_t cap, int nq_launch, const void* V, int d,
+int hdb_launch_rescore_euclid(unsigned long long* cand, const uint32_t* cnt, uint32_t cap, int nq_launch, const void* V, int dtype, int d,
                               const float* Q, int q0, const float* bias, void* stream);
 }
 
@@ -374,7 +374,7 @@ static int run_scan(hdb_index* ix, ScanArgs& a, int mode, int cq, const QueryBuf
     if (is_bits_metric(a.metric)) {
         LAUNCH_TRY(hdb_launch_hamming(&a, mode, cq, ix->bits, ix->bits_npad, ix->W, qb.qbits, st));
     } else if (mfma) {
-        LAUNCH_TRY(hdb_launch_mfma_scan(&a, mode, cq, qb.q16, ix->sqnorm, qb.qsq, qb.qscl, (int)ix->max_blocks, st));
+        LAUNCH_TRY(hdb_launch_mfma_scan(&a, ix->dtype, mode, cq, qb.q16, ix->sqnorm, qb.qsq, qb.qscl, (int)ix->max_blocks, st));
     } else {
         LAUNCH_TRY(hdb_launch_scan(&a, ix->dtype, mode, cq, (int)ix->max_blocks, st));
     }
@@ -460,9 +460,12 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     if (is_ham && !small && !ix->bits_fused) exact = true;
     if (ix->force_exact && !small) exact = true;
     if (!small && (int64_t)kk * 32 > n) exact = true;        // k is a large share of the rows: a sampled threshold cannot help
-    const bool mfma = ix->use_mfma && !is_ham && !small && nq >= ix->mfma_min_q &&
+    // fp32 matrices: the VALU scan serves up to 4 queries in one pass at HBM speed; the fp32 MFMA scan (matrix-pipe
+    // bound at 157 TFLOP/s) takes over where a second VALU pass would start
+    const int64_t min_q = ix->dtype == HDB_F32 ? std::max<int64_t>(ix->mfma_min_q, 5) : ix->mfma_min_q;
+    const bool mfma = ix->use_mfma && !is_ham && !small && nq >= min_q &&
                       hdb_mfma_supported(ix->dtype, ix->d, is_pearson ? (int)HDB_COSINE : metric);
-    const int tile_rows = mfma ? hdb_mfma_tile_rows(ix->d) : 16;
+    const int tile_rows = mfma ? hdb_mfma_tile_rows(ix->dtype, ix->d) : 16;
 
     // ---- plan the chunking --------------------------------------------------------------------
     int64_t s_tiles = 0, s_stride = 1; uint32_t m = 0;
@@ -498,7 +501,8 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     float* sbuf = b.take<float>((size_t)cq_max * (exact && !small ? ld_n : ld_s));
 
     // the MFMA scan multiplies with fp16 queries: written by the same kernel (pearson converts its centred copy later)
-    const bool q16_in_prep = mfma && !is_pearson && !full_sort;
+    const bool f16_queries = mfma && ix->dtype == HDB_F16;          // fp32 matrices multiply with the float32 queries as they are
+    const bool q16_in_prep = f16_queries && !is_pearson && !full_sort;
     LAUNCH_TRY(hdb_launch_qprep(dev_Q, nq, ix->d, f64, qinv, qsq, qnan, q16_in_prep ? q16 : nullptr, qscl, st));
     if (is_ham) {
         rc = ensure_bits(ix, st); if (rc) return rc;
@@ -565,8 +569,8 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     for (int q0 = 0; q0 < nq; q0 += cq_max) {
         const int cq = std::min(cq_max, nq - q0);
         ix->st_chunks++;
-        if (mfma && !q16_ready) { LAUNCH_TRY(hdb_launch_q_to_f16((const float*)Qeff, nq, ix->d, q16, qscl, st)); q16_ready = true; }
-        QueryBufs qb{qinv, qsq, qbits, q16, qscl};
+        if (f16_queries && !q16_ready) { LAUNCH_TRY(hdb_launch_q_to_f16((const float*)Qeff, nq, ix->d, q16, qscl, st)); q16_ready = true; }
+        QueryBufs qb{qinv, qsq, qbits, f16_queries ? q16 : Qeff, f16_queries ? qscl : nullptr};
         ScanArgs a; base_args(ix, a, Qeff, metric_eff);
         if (is_pearson) a.inv_norm = ix->pscale;
         a.q0 = q0; a.bias = bias_eff; a.mask = mask_eff;
@@ -613,7 +617,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
             LAUNCH_TRY(hdb_launch_collect(sbuf, n, ld_n, cq, hist, npass, kk, cnt, cand, HDB_CAND_CAP, tie_info, st));
         }
         if (mfma && metric == HDB_EUCLIDEAN)     // the MFMA path scores through ||v||^2+||q||^2-2v.q: redo near-duplicates directly
-            LAUNCH_TRY(hdb_launch_rescore_euclid(cand, cnt, HDB_CAND_CAP, cq, ix->V, ix->d, (const float*)dev_Q, q0, ix->bias, st));
+            LAUNCH_TRY(hdb_launch_rescore_euclid(cand, cnt, HDB_CAND_CAP, cq, ix->V, ix->dtype, ix->d, (const float*)dev_Q, q0, ix->bias, st));
         LAUNCH_TRY(hdb_launch_finalize(cand, cnt, HDB_CAND_CAP, cq, (uint32_t)k, kk, ix->row_base,
                                        dev_idx + (int64_t)q0 * k, dev_score + (int64_t)q0 * k,
                                        dev_status ? dev_status + q0 : nullptr, qnan + q0, st));

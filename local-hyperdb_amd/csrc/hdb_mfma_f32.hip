@@ -1,0 +1,18 @@
+// hdb_mfma_f32.hip -- fp32 instantiations of the MFMA row scan (hdb_mfma_kernel.h): v_mfma_f32_16x16x4_f32, exact
+// fp32 products and accumulation, so batches on float32 matrices (the reference's default fp_precision,
+// hyperdb.py:51) keep the 1e-5 parity contract while up to 128 queries ride on one pass over V instead of 4.
+#include "hdb_mfma_kernel.h"
+
+extern "C" int hdb_launch_mfma_scan_f32(const ScanArgs* args, int mode, int nq_launch, const void* q, const float* sqnorm,
+                                        const float* qsq, int blocks, void* stream) {
+    const ScanArgs& a = *args;
+    hipStream_t st = (hipStream_t)stream;
+    switch (a.d) {
+        case 128: return launch_mode<float, 16, 1, 128, 64>(a, mode, q, sqnorm, qsq, nullptr, nq_launch, blocks, st);
+        case 256: return launch_mode<float, 16, 1, 256, 32>(a, mode, q, sqnorm, qsq, nullptr, nq_launch, blocks, st);
+        case 384: return launch_mode<float, 16, 1, 384, 32>(a, mode, q, sqnorm, qsq, nullptr, nq_launch, blocks, st);
+        case 512: return launch_mode<float, 16, 1, 512, 16>(a, mode, q, sqnorm, qsq, nullptr, nq_launch, blocks, st);
+        case 768: return launch_mode<float, 16, 1, 768, 16>(a, mode, q, sqnorm, qsq, nullptr, nq_launch, blocks, st);
+        default: return (int)hipErrorNotSupported;
+    }
+}

@@ -759,6 +759,52 @@ def test_row_mask_mfma_equals_valu(orc, keep):
         ix.close()
 
 
+@pytest.mark.parametrize("d,nq,metric,bias", [(384, 64, "cosine_similarity", False), (384, 130, "dot_product", True),
+                                              (128, 5, "euclidean_metric", False), (256, 33, "cosine_similarity", True),
+                                              (512, 17, "euclidean_metric", True), (768, 128, "dot_product", False),
+                                              (384, 9, "pearson_correlation", False)])
+def test_fp32_mfma_batches_match_valu_and_oracle(orc, d, nq, metric, bias):
+    """float32 matrices (the reference's default fp_precision): batches of 5+ queries ride the fp32 MFMA scan
+    (v_mfma_f32_16x16x4_f32, exact fp32 products) and must agree with the VALU scan and the oracle to 1e-5."""
+    from hyperdb._native import GpuIndex, METRIC_IDS
+    rng = np.random.default_rng(d * 1000 + nq)
+    n, k = 50_000 + 13, 50
+    V = rng.standard_normal((n, d)).astype(np.float32)
+    Q = rng.standard_normal((nq, d)).astype(np.float32)
+    Q[0] = V[n - 2]                                             # exact duplicate of a row in the ragged last tile
+    Q[1] = V[77] + 0.05 * rng.standard_normal(d).astype(np.float32)
+    ts = 1.7e9 + rng.uniform(0, 30 * 86400.0, size=n)
+    ix = GpuIndex(V)
+    try:
+        b = None
+        if bias:
+            ix.set_recency(ts, 0.5)
+            b = 0.5 * np.exp(ts - ts.max())
+        mid = METRIC_IDS[metric]
+        mi, ms, mst = ix.topk_device(Q, k, mid)
+        assert ix.stat("mfma") == 1 and ix.stat("path") == 1 and int(mst.abs().sum().item()) == 0
+        ei, es, _ = ix.topk_device(Q, k, mid, exact=True)
+        import torch
+        assert torch.equal(mi, ei) and torch.equal(ms, es)
+        ix.set_option("use_mfma", 0)
+        vi, vs, _ = ix.topk_device(Q, k, mid)
+        ix.set_option("use_mfma", 1)
+        assert ix.stat("mfma") == 0
+        mi_h, ms_h, vi_h, vs_h = mi.cpu().numpy(), ms.cpu().numpy(), vi.cpu().numpy(), vs.cpu().numpy()
+        for qi in range(nq):
+            assert orc.same_result_modulo_ties(mi_h[qi], ms_h[qi], vi_h[qi], vs_h[qi], 1e-5), qi
+        for qi in (0, 1, nq - 1):
+            orc.check_topk(mi_h[qi], ms_h[qi], V, Q[qi], metric, k, bias=b, tol=1e-5)
+        if metric == "euclidean_metric" and not bias:
+            assert mi_h[0][0] == n - 2 and abs(ms_h[0][0] - 1.0) < 1e-6
+            assert mi_h[1][0] == 77
+        # up to 4 queries stay on the VALU scan (one pass at HBM speed)
+        ix.topk_device(Q[:4], k, mid)
+        assert ix.stat("mfma") == 0
+    finally:
+        ix.close()
+
+
 def test_topk_host_pinned_and_pageable_records(orc):
     """hdb_topk_host stores into pinned records from the kernels themselves and copies for pageable ones; same bytes."""
     import ctypes, torch
