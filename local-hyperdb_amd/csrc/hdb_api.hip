@@ -52,7 +52,7 @@ int hdb_sort_temp_bytes(int64_t n, size_t* bytes);
 int hdb_launch_full_sort(const float* scores, int64_t n, int64_t k, int64_t row_base, uint32_t* work, void* temp, size_t temp_bytes,
                          int64_t* idx_out, float* score_out, void* stream);
 int hdb_launch_rescore_euclid(unsigned long long* cand, const uint32_t* cnt, uint32_t cap, int nq_launch, const void* V, int dtype, int d,
-                              const float* Q, int q0, const float* bias, void* stream);
+                              const float* Q, const float* qsq, int q0, const float* bias, void* stream);
 }
 
 static thread_local std::string g_err;
@@ -617,7 +617,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
             LAUNCH_TRY(hdb_launch_collect(sbuf, n, ld_n, cq, hist, npass, kk, cnt, cand, HDB_CAND_CAP, tie_info, st));
         }
         if (mfma && metric == HDB_EUCLIDEAN)     // the MFMA path scores through ||v||^2+||q||^2-2v.q: redo near-duplicates directly
-            LAUNCH_TRY(hdb_launch_rescore_euclid(cand, cnt, HDB_CAND_CAP, cq, ix->V, ix->dtype, ix->d, (const float*)dev_Q, q0, ix->bias, st));
+            LAUNCH_TRY(hdb_launch_rescore_euclid(cand, cnt, HDB_CAND_CAP, cq, ix->V, ix->dtype, ix->d, (const float*)dev_Q, qsq, q0, ix->bias, st));
         LAUNCH_TRY(hdb_launch_finalize(cand, cnt, HDB_CAND_CAP, cq, (uint32_t)k, kk, ix->row_base,
                                        dev_idx + (int64_t)q0 * k, dev_score + (int64_t)q0 * k,
                                        dev_status ? dev_status + q0 : nullptr, qnan + q0, st));

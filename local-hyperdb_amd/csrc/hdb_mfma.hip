@@ -38,23 +38,27 @@ __global__ __launch_bounds__(64) void hdb_q_to_f16_kernel(const float* Q, int nq
     if (threadIdx.x == 0) qscl[q] = 1.f / scale;
 }
 
-// Euclidean scores from the MFMA path come from ||v||^2 + ||q||^2 - 2 v.q, which cancels when v ~ q (an
-// exact duplicate scores 1/(1+~0.01) instead of 1).  Candidates whose similarity exceeds a threshold (below)
-// are re-scored from the stored row with the direct difference, like the reference (:49).  One wave per entry.
+// Euclidean scores from the MFMA path come from ||v||^2 + ||q||^2 - 2 v.q, which cancels when v ~ q (an exact
+// duplicate scores 1/(1+~0.01) instead of 1).  Candidates whose squared distance is below 5 % of ||q||^2 -- where
+// the rounding of the expansion, ~1e-6 (||v||^2 + ||q||^2), exceeds 4e-5 of the distance itself -- are re-scored
+// from the stored row with the direct difference, like the reference (:49); beyond that the expansion is good to
+// 5e-6 in the similarity.  One wave per entry.
 template <typename T, bool HAS_BIAS>
 __global__ __launch_bounds__(256) void hdb_rescore_euclid_kernel(unsigned long long* cand, const uint32_t* cnt, uint32_t cap,
-                                                                 const T* V, int d, const float* Q, int q0,
+                                                                 const T* V, int d, const float* Q, const float* qsq, int q0,
                                                                  const float* bias) {
     const int ql = blockIdx.y, lane = threadIdx.x & 63;
     const uint32_t n = cnt[ql] < cap ? cnt[ql] : cap;
     const float* qv = Q + (int64_t)(q0 + ql) * d;
+    const float close2 = 0.05f * qsq[q0 + ql];
     for (uint32_t e = blockIdx.x * 4 + (threadIdx.x >> 6); e < n; e += gridDim.x * 4) {
         const unsigned long long ent = cand[(int64_t)ql * cap + e];
         const uint32_t row = 0xFFFFFFFFu - (uint32_t)(ent & 0xFFFFFFFFull);
         float s = hdb_key2f((uint32_t)(ent >> 32));
         const float b = HAS_BIAS ? bias[row] : 0.f;
-        // fp16 data (contract 1e-3): similarity above 0.5 (distance < 1); fp32 data (1e-5): above 0.05 (distance < 19)
-        if (s - b > (sizeof(T) == 2 ? 0.5f : 0.05f)) {             // wave-uniform: one entry per wave
+        const float sim = s - b;                                   // 1 / (1 + dist) in (0, 1]; -inf for an excluded row
+        const float dist = 1.f / sim - 1.f;
+        if (sim > 0.f && dist * dist < close2) {                   // wave-uniform: one entry per wave
             float acc = 0.f;
             for (int k = lane; k < d; k += 64) { const float df = (float)V[(int64_t)row * d + k] - qv[k]; acc += df * df; }
 #pragma unroll
@@ -136,15 +140,15 @@ extern "C" int hdb_launch_q_to_f16(const float* Q, int nq, int d, void* q16, flo
 }
 
 extern "C" int hdb_launch_rescore_euclid(unsigned long long* cand, const uint32_t* cnt, uint32_t cap, int nq_launch, const void* V,
-                                         int dtype, int d, const float* Q, int q0, const float* bias, void* stream) {
+                                         int dtype, int d, const float* Q, const float* qsq, int q0, const float* bias, void* stream) {
     const dim3 grid(64, nq_launch);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == HDB_F16) {
-        if (bias) hipLaunchKernelGGL((hdb_rescore_euclid_kernel<_Float16, true>), grid, dim3(256), 0, st, cand, cnt, cap, (const _Float16*)V, d, Q, q0, bias);
-        else hipLaunchKernelGGL((hdb_rescore_euclid_kernel<_Float16, false>), grid, dim3(256), 0, st, cand, cnt, cap, (const _Float16*)V, d, Q, q0, bias);
+        if (bias) hipLaunchKernelGGL((hdb_rescore_euclid_kernel<_Float16, true>), grid, dim3(256), 0, st, cand, cnt, cap, (const _Float16*)V, d, Q, qsq, q0, bias);
+        else hipLaunchKernelGGL((hdb_rescore_euclid_kernel<_Float16, false>), grid, dim3(256), 0, st, cand, cnt, cap, (const _Float16*)V, d, Q, qsq, q0, bias);
     } else {
-        if (bias) hipLaunchKernelGGL((hdb_rescore_euclid_kernel<float, true>), grid, dim3(256), 0, st, cand, cnt, cap, (const float*)V, d, Q, q0, bias);
-        else hipLaunchKernelGGL((hdb_rescore_euclid_kernel<float, false>), grid, dim3(256), 0, st, cand, cnt, cap, (const float*)V, d, Q, q0, bias);
+        if (bias) hipLaunchKernelGGL((hdb_rescore_euclid_kernel<float, true>), grid, dim3(256), 0, st, cand, cnt, cap, (const float*)V, d, Q, qsq, q0, bias);
+        else hipLaunchKernelGGL((hdb_rescore_euclid_kernel<float, false>), grid, dim3(256), 0, st, cand, cnt, cap, (const float*)V, d, Q, qsq, q0, bias);
     }
     return (int)hipGetLastError();
 }

@@ -63,7 +63,7 @@ template <> struct MfmaShape<16, float> {
 // METRIC: 0 dot, 1 cosine (aux0 = 1/||v||), 2 euclidean similarity (aux0 = ||v||^2)
 // Fragment maps (lane l):  MF=32: row/query l&31, k = 16s + 8(l>>5) + j, C reg e -> row (e&3) + 8(e>>2) + 4(l>>5)
 //                          MF=16: row/query l&15, k = 32s + 8(l>>4) + j, C reg e -> row 4(l>>4) + e
-template <typename E, int MF, int QT, int D, int R, int MODE, int METRIC, bool HAS_BIAS>
+template <typename E, int MF, int QT, int D, int R, int RS, int MODE, int METRIC, bool HAS_BIAS>
 __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __restrict__ q16,
                                                        const float* __restrict__ aux0g, const float* __restrict__ qsq, const float* __restrict__ qscl,
                                                        int nq_end) {
@@ -76,14 +76,16 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
     constexpr int CPR = ROWB / 16;              // 16-byte chunks per row
     constexpr int CPS = Shape::CPS;             // chunks per k-step (2 or 4)
     constexpr int KS = CPR / CPS;               // k-steps (one fragment read each)
-    constexpr int RT = R / MF;                  // MFMA row tiles per stage
+    // RS > 1 ("row split"): RS consecutive waves share one query group and take every RS-th row tile of the stage each,
+    // so that few queries still spread their MFMAs over all four SIMDs (fp32 MFMAs bind long before HBM does)
+    constexpr int RT = R / MF / RS;             // MFMA row tiles per stage and wave
     constexpr int STAGE = R * ROWB;             // bytes of V per stage
     constexpr int NG = R * CPR / 64 / 8;        // LDS-DMA instructions per wave per tile
     constexpr bool AUX0 = METRIC != 0;
     constexpr int NLOADA = NG;
     constexpr int NLOADB = NG + (AUX0 ? 1 : 0) + (HAS_BIAS ? 1 : 0);     // B waves also stage the per-row aux values
     constexpr int QPW = MF * QT;                // queries per wave (QT query tiles share every A fragment)
-    static_assert(R % MF == 0 && R <= 64 && (R * CPR) % 512 == 0 && ROWB % 256 == 0 && KS % NG == 0, "tile geometry");
+    static_assert(R % (MF * RS) == 0 && 8 % RS == 0 && R <= 64 && (R * CPR) % 512 == 0 && ROWB % 256 == 0 && KS % NG == 0, "tile geometry");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* auxbuf = reinterpret_cast<float*>(smem + 3 * STAGE);                    // [3 stages][2][64]
@@ -97,7 +99,8 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
     const int h = lane / MF;                    // which 8-element k-chunk of the step (0..CPS-1)
 
     // ---- this wave's queries --------------------------------------------------------------------
-    const int qw0 = a.q0 + blockIdx.y * (8 * QPW) + w * QPW;
+    const int part = RS > 1 ? w % RS : 0;       // which row tiles of a stage this wave multiplies: part, part + RS, ...
+    const int qw0 = a.q0 + blockIdx.y * ((8 / RS) * QPW) + (w / RS) * QPW;
     const bool wave_active = qw0 < nq_end;
     bool q_ok[QT];
     int ql[QT];
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
     // Then A stages its half of tile i+2 right after the barrier while B already multiplies, and B stages its
     // half after its MFMA phase while A finishes -- the two waves of a SIMD never issue LDS-DMA (~90 cycles of
     // blocked issue per 1 KiB piece) at the same time.  Otherwise (HBM-bound) everyone stages right away.
-    const bool heavy = (nq_end - (a.q0 + (int)blockIdx.y * (8 * QPW))) > 4 * QPW;
+    const bool heavy = (nq_end - (a.q0 + (int)blockIdx.y * ((8 / RS) * QPW))) > (4 / RS) * QPW;
 
     // ---- staging geometry (per lane, fixed for the whole kernel) -----------------------------------
     int g_off[NG];
@@ -207,10 +210,10 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
     const unsigned int cbq_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(cbq);
     // per-lane LDS read address: row rl of a row tile; chunk (CPS*s + h) ^ rx of k-step s is at byte
     // ((16*CPS*s) ^ hx) of the row image, hx = (h ^ rx) << 4  (CPS*s and h occupy disjoint bits)
-    const unsigned int rd_base = (unsigned int)(rl * CPR * 16);
+    const unsigned int rd_base = (unsigned int)((rl + part * MF) * CPR * 16);
     const unsigned int hx = (unsigned int)((h ^ (rl & 15)) << 4);
     // first of the 4 consecutive tile rows this lane's accumulator group g holds
-    auto grp_row = [&](int rt, int g) { return MF == 32 ? rt * 32 + 8 * g + 4 * h : rt * 16 + 4 * h; };
+    auto grp_row = [&](int rt, int g) { const int rg = part + RS * rt; return MF == 32 ? rg * 32 + 8 * g + 4 * h : rg * 16 + 4 * h; };
 
     // threshold in the domain the epilogue compares in (see below); +inf for padding lanes
     float thr_cmp[QT];
@@ -324,9 +327,9 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
             auto fetch = [&](int s, Vec (&dst)[RT]) {
                 const unsigned int ad = sb_addr + ((unsigned int)(16 * CPS * s) ^ hx);
                 asm volatile("ds_read_b128 %0, %1" : "=v"(dst[0]) : "v"(ad));
-                if constexpr (RT > 1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[1]) : "v"(ad), "i"(MF * CPR * 16));
-                if constexpr (RT > 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[2]) : "v"(ad), "i"(2 * MF * CPR * 16));
-                if constexpr (RT > 3) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[3]) : "v"(ad), "i"(3 * MF * CPR * 16));
+                if constexpr (RT > 1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[1]) : "v"(ad), "i"(RS * MF * CPR * 16));
+                if constexpr (RT > 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[2]) : "v"(ad), "i"(2 * RS * MF * CPR * 16));
+                if constexpr (RT > 3) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[3]) : "v"(ad), "i"(3 * RS * MF * CPR * 16));
             };
             // wait until at most `pend` k-steps of fragment reads are outstanding: lgkmcnt(pend*RT)
             auto wait_frag = [&](int pend, Vec (&f)[RT]) {
@@ -436,9 +439,9 @@ static size_t mfma_lds_bytes(int stage_bytes) {
     return (size_t)3 * stage_bytes + 3 * 2 * 64 * 4 + (size_t)HDB_MFMA_CB * 8 + (size_t)HDB_MFMA_CB * 2 + 64;
 }
 
-template <typename E, int MF, int QT, int D, int R, int MODE, int METRIC, bool HAS_BIAS>
+template <typename E, int MF, int QT, int D, int R, int RS, int MODE, int METRIC, bool HAS_BIAS>
 static int launch_one(const ScanArgs& a, const void* q16, const float* aux0, const float* qsq, const float* qscl, int nq_launch, int blocks, hipStream_t st) {
-    auto kern = hdb_mfma_kernel<E, MF, QT, D, R, MODE, METRIC, HAS_BIAS>;
+    auto kern = hdb_mfma_kernel<E, MF, QT, D, R, RS, MODE, METRIC, HAS_BIAS>;
     const size_t lds = mfma_lds_bytes(R * D * (int)sizeof(E));
     static bool attr_done = false;          // per instantiation
     if (!attr_done) {
@@ -446,26 +449,26 @@ static int launch_one(const ScanArgs& a, const void* q16, const float* aux0, con
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    const dim3 grid(blocks, (nq_launch + 8 * MF * QT - 1) / (8 * MF * QT));
+    const dim3 grid(blocks, (nq_launch + (8 / RS) * MF * QT - 1) / ((8 / RS) * MF * QT));
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a, (const E*)q16, aux0, qsq, qscl, a.q0 + nq_launch);
     return (int)hipGetLastError();
 }
 
-template <typename E, int MF, int QT, int D, int R, int MODE>
+template <typename E, int MF, int QT, int D, int R, int RS, int MODE>
 static int launch_metric(const ScanArgs& a, const void* q16, const float* sqnorm, const float* qsq, const float* qscl, int nq_launch, int blocks, hipStream_t st) {
     const bool b = a.bias != nullptr;
-    if (a.metric == HDB_DOT) return b ? launch_one<E, MF, QT, D, R, MODE, 0, true>(a, q16, nullptr, qsq, qscl, nq_launch, blocks, st)
-                                      : launch_one<E, MF, QT, D, R, MODE, 0, false>(a, q16, nullptr, qsq, qscl, nq_launch, blocks, st);
-    if (a.metric == HDB_COSINE) return b ? launch_one<E, MF, QT, D, R, MODE, 1, true>(a, q16, a.inv_norm, qsq, qscl, nq_launch, blocks, st)
-                                         : launch_one<E, MF, QT, D, R, MODE, 1, false>(a, q16, a.inv_norm, qsq, qscl, nq_launch, blocks, st);
-    if (a.metric == HDB_EUCLIDEAN) return b ? launch_one<E, MF, QT, D, R, MODE, 2, true>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st)
-                                            : launch_one<E, MF, QT, D, R, MODE, 2, false>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
+    if (a.metric == HDB_DOT) return b ? launch_one<E, MF, QT, D, R, RS, MODE, 0, true>(a, q16, nullptr, qsq, qscl, nq_launch, blocks, st)
+                                      : launch_one<E, MF, QT, D, R, RS, MODE, 0, false>(a, q16, nullptr, qsq, qscl, nq_launch, blocks, st);
+    if (a.metric == HDB_COSINE) return b ? launch_one<E, MF, QT, D, R, RS, MODE, 1, true>(a, q16, a.inv_norm, qsq, qscl, nq_launch, blocks, st)
+                                         : launch_one<E, MF, QT, D, R, RS, MODE, 1, false>(a, q16, a.inv_norm, qsq, qscl, nq_launch, blocks, st);
+    if (a.metric == HDB_EUCLIDEAN) return b ? launch_one<E, MF, QT, D, R, RS, MODE, 2, true>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st)
+                                            : launch_one<E, MF, QT, D, R, RS, MODE, 2, false>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
     return (int)hipErrorNotSupported;
 }
 
-template <typename E, int MF, int QT, int D, int R>
+template <typename E, int MF, int QT, int D, int R, int RS = 1>
 static int launch_mode(const ScanArgs& a, int mode, const void* q16, const float* sqnorm, const float* qsq, const float* qscl, int nq_launch, int blocks, hipStream_t st) {
-    if (mode == 0) return launch_metric<E, MF, QT, D, R, 0>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
-    return launch_metric<E, MF, QT, D, R, 1>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
+    if (mode == 0) return launch_metric<E, MF, QT, D, R, RS, 0>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
+    return launch_metric<E, MF, QT, D, R, RS, 1>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
 }
 
