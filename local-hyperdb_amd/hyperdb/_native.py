@@ -289,6 +289,9 @@ class GpuIndex:
     def _query_tensor(self, q, batched):
         qdt = torch.float64 if self.dtype == HDB_F64 else torch.float32
         if isinstance(q, torch.Tensor):
+            if batched and q.dtype == qdt and q.dim() == 2 and q.shape[1] == self.d and q.device == self.device \
+                    and q.is_contiguous():
+                return q                                 # the per-query fast path: nothing to convert
             t = q.to(self.device, qdt)
         else:
             t = torch.from_numpy(np.ascontiguousarray(np.asarray(q, dtype=np.float64))).to(self.device, qdt)
@@ -341,17 +344,17 @@ class GpuIndex:
         rare exact re-run.  Returns numpy VIEWS (idx int64 [nq,k], score float32 [nq,k], status int32 [nq]) that are
         overwritten by the next call with the same (nq, k)."""
         qt = self._query_tensor(Q, batched=True)
-        nq = int(qt.shape[0])
-        nb = packed_bytes(nq, k)
-        host = _pinned.get(nb)
-        if host is None:
-            host = torch.empty(nb, dtype=torch.uint8, pin_memory=True)
-            _pinned[nb] = host
-        _check(_lib.hdb_topk_host(self._h, ctypes.c_void_p(qt.data_ptr()), nq, int(k), int(metric_id),
-                                  ctypes.c_void_p(host.data_ptr()), _stream_ptr(self.device)), "hdb_topk_host")
-        h = host.numpy()
-        return (h[:nq * k * 8].view(np.int64).reshape(nq, k), h[nq * k * 8:nq * k * 12].view(np.float32).reshape(nq, k),
-                h[nq * k * 12:nq * k * 12 + nq * 4].view(np.int32))
+        nq, k = int(qt.shape[0]), int(k)
+        slot = _host_records.get((nq, k))
+        if slot is None:                                 # pinned record + its numpy views, built once per (nq, k)
+            host = torch.empty(packed_bytes(nq, k), dtype=torch.uint8, pin_memory=True)
+            h = host.numpy()
+            slot = (host, ctypes.c_void_p(host.data_ptr()), h[:nq * k * 8].view(np.int64).reshape(nq, k),
+                    h[nq * k * 8:nq * k * 12].view(np.float32).reshape(nq, k), h[nq * k * 12:nq * k * 12 + nq * 4].view(np.int32))
+            _host_records[(nq, k)] = slot
+        _check(_lib.hdb_topk_host(self._h, ctypes.c_void_p(qt.data_ptr()), nq, k, int(metric_id), slot[1],
+                                  _stream_ptr(self.device)), "hdb_topk_host")
+        return slot[2], slot[3], slot[4]
 
     def topk(self, Q, k, metric_id):
         """Top-k of a query batch on the host: (int64 [nq,k], float32 [nq,k]) (copies)."""
@@ -366,6 +369,7 @@ def packed_bytes(nq, k):
 
 
 _pinned = {}
+_host_records = {}          # (nq, k) -> (pinned tensor, its pointer, idx / score / status views) for GpuIndex.topk_views
 
 
 def record_to_host(record, nq, k):
