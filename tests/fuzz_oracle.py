@@ -1,7 +1,9 @@
 """GPU result vs the numpy oracle (float64-exact comparator) on random shapes: all seven metrics, fp16/fp32/fp64,
 MFMA and odd dimensions, single queries and batches, optional recency bias.  Test infrastructure (imports oracle/)."""
 import sys, time
-sys.path.insert(0, 'local-hyperdb_amd'); sys.path.insert(0, '.')
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'local-hyperdb_amd')); sys.path.insert(0, ROOT)
 import numpy as np, torch
 from hyperdb._native import GpuIndex, METRIC_IDS
 from oracle import ranking_oracle as orc
