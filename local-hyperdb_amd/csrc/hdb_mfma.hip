@@ -103,6 +103,9 @@ extern "C" int hdb_mfma_supported(int dtype, int d, int metric) {
 static int g_mfma_variant = 16;
 extern "C" void hdb_set_mfma_variant(int v) { if (v == 16 || v == 32) g_mfma_variant = v; }
 
+extern "C" int hdb_mfma_qt2_supported(int d);
+extern "C" int hdb_launch_mfma_scan_f16_qt2(const ScanArgs* args, int mode, int nq_launch, const void* q16, const float* sqnorm,
+                                            const float* qsq, const float* qscl, int blocks, void* stream);
 extern "C" int hdb_launch_mfma_scan_f32(const ScanArgs* args, int mode, int nq_launch, const void* q, const float* sqnorm,
                                         const float* qsq, int blocks, void* stream);
 
@@ -118,6 +121,8 @@ extern "C" int hdb_launch_mfma_scan(const ScanArgs* args, int dtype, int mode, i
     if (blocks < 1) blocks = 1;
     if (dtype == HDB_F32) return hdb_launch_mfma_scan_f32(args, mode, nq_launch, q16, sqnorm, qsq, blocks, stream);
     if (dtype != HDB_F16) return (int)hipErrorNotSupported;
+    if (nq_launch > 128 && hdb_mfma_qt2_supported(a.d) && g_mfma_variant != 32)
+        return hdb_launch_mfma_scan_f16_qt2(args, mode, nq_launch, q16, sqnorm, qsq, qscl, blocks, stream);
     switch (a.d) {
         case 128: return launch_mode<_Float16, 16, 1, 128, 64>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
         case 256: return launch_mode<_Float16, 16, 1, 256, 64>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);

@@ -565,7 +565,9 @@ def test_mfma_with_recency_bias(orc):
                                               (512, 33, "cosine_similarity", True), (640, 16, "dot_product", True),
                                               (384, 96, "euclidean_metric", True), (1024, 48, "cosine_similarity", False),
                                               (1024, 128, "euclidean_metric", True), (1536, 32, "dot_product", False),
-                                              (1536, 70, "cosine_similarity", True)])
+                                              (1536, 70, "cosine_similarity", True), (256, 200, "cosine_similarity", False),
+                                              (512, 256, "euclidean_metric", True), (640, 129, "dot_product", False),
+                                              (128, 256, "dot_product", True)])
 def test_mfma_shapes_and_euclidean(orc, d, nq, metric, bias):
     """Config-5 shaped case (d=768, Q=64, euclidean + time decay) and the other MFMA geometries."""
     import torch
