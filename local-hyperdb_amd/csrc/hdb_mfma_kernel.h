@@ -9,9 +9,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define HDB_MFMA_CB 1024            // LDS candidate list entries per workgroup
-#ifndef HDB_PF_QT2
-#define HDB_PF_QT2 2
-#endif
 
 #define HDB_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define HDB_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -322,7 +319,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
             // lgkmcnt(n*RT) = "all but the n*RT newest LDS ops are back" = the oldest pending step's fragments;
             // stray scalar loads can only make that wait longer, never shorter.
             const unsigned int sb_addr = smem_addr + (unsigned int)(st_cur * STAGE) + rd_base;
-            constexpr int PF = HDB_PF_QT2 > 0 && QT == 2 ? HDB_PF_QT2 : 3;   // k-steps of LDS prefetch (PF+1 fragment sets)
+            constexpr int PF = QT == 2 ? 2 : 3;                // k-steps of LDS prefetch (PF+1 fragment sets; two query tiles: registers)
             Vec abuf[PF + 1][RT];
             auto fetch = [&](int s, Vec (&dst)[RT]) {
                 const unsigned int ad = sb_addr + ((unsigned int)(16 * CPS * s) ^ hx);
