@@ -3,8 +3,10 @@
 Scope: ONLY what sits either side of the hot path -- the constructor that
 takes documents + precomputed vectors, ``query()`` with the reference's signature and return shapes,
 and the ~30 lines of ``_execute_query`` around the ranking call (hyperdb.py:1461-1469, :1541-1575).
-Everything else the reference class does (sentence-transformer embedding, Annoy, pickle/sqlite
-persistence, text filters) is out of scope and is NOT re-implemented here.
+Also here, from the "next" rows of SURVEY.md section 8f: ``save`` / ``load`` in the reference's own pickle, json and
+sqlite layouts (hyperdb.py:769-1005) so an existing database file goes straight into HBM, and the ``sentence``
+filter (a host predicate).  Everything else the reference class does (sentence-transformer embedding, Annoy, the
+``key`` filter that re-embeds sub-documents) is out of scope and is NOT re-implemented here.
 
 Differences from the reference, all deliberate:
   * the N x d matrix is registered once on the GPU (``GpuIndex``) -- no per-query NaN scan, copy or
@@ -14,8 +16,9 @@ Differences from the reference, all deliberate:
     O(N) Python index rebuild on every add/remove (hyperdb.py:218-220);
   * ranked rows map to documents by row id, O(k), instead of ``self.documents.index(document)``
     (hyperdb.py:1568, O(N) dict comparisons per hit);
-  * ``filters``: ``skip_doc`` and ``metadata`` equality filters become a device row mask; the text filters
-    (``key``, ``sentence``) need the embedding model and raise NotImplementedError;
+  * ``filters``: ``skip_doc``, ``metadata`` equality and ``sentence`` (whole-word, hyperdb.py:1136-1176) filters
+    become a device row mask; the ``key`` filter re-embeds sub-documents (hyperdb.py:1087) and raises
+    NotImplementedError without a model;
   * strings can be queried only when an ``embedding_function`` is supplied (no model download).
 Kept from the reference: argument names and defaults, metric whitelist and messages, the top_k warning,
 ``(document, score, source_index)`` / ``document`` return shapes, the LRU result cache, and the DOUBLE
@@ -24,7 +27,14 @@ ranking_algorithm.py:183).
 """
 from __future__ import annotations
 
+import gzip
+import json
+import pickle
+import re
+import sqlite3
+import string
 from collections import OrderedDict
+from contextlib import closing
 
 import numpy as np
 
@@ -220,9 +230,126 @@ class HyperDB:
                     nested = key.split('.')
                     keep &= np.array([self.get_nested_value(doc, nested) == want if isinstance(doc, dict) else False
                                       for doc in self.documents])
+            elif name == 'sentence':
+                wanted = params if isinstance(params, (list, tuple)) else [params]
+                token_sets = [self.tokenize(w) for w in wanted]              # each filter tokenised once (:1164-1165)
+                keep &= np.array([all(self.recursive_sentence_filter(doc, ts) for ts in token_sets) for doc in self.documents],
+                                 dtype=bool)
+            elif name == 'key':
+                raise NotImplementedError("filter 'key' re-embeds sub-documents (hyperdb.py:1087): needs the embedding "
+                                          "pipeline, which is out of scope here")
             else:
-                raise NotImplementedError(f"filter '{name}' needs the text/embedding pipeline, which is out of scope here")
+                raise ValueError(f"Invalid filter name {name}")                # hyperdb.py:1279-1280
         return keep
+
+    # ---------------------------------------------------------------- sentence filter (hyperdb.py:1136-1176)
+    @staticmethod
+    def tokenize(text):
+        """Lower-cased word set of a string with punctuation removed (hyperdb.py:1136-1141)."""
+        text = ''.join(c for c in text if c not in string.punctuation)
+        return set(re.findall(r'\b\w+\b', text.lower()))
+
+    @classmethod
+    def recursive_sentence_filter(cls, obj, sentence_filter_tokens):
+        """True when some string inside ``obj`` (dicts and lists are searched recursively) contains every token
+        as a whole word (hyperdb.py:1143-1158)."""
+        if isinstance(obj, dict):
+            return any(cls.recursive_sentence_filter(v, sentence_filter_tokens) for v in obj.values())
+        if isinstance(obj, list):
+            return any(cls.recursive_sentence_filter(v, sentence_filter_tokens) for v in obj)
+        if isinstance(obj, str):
+            return sentence_filter_tokens.issubset(cls.tokenize(obj))
+        return False
+
+    # ---------------------------------------------------------------- persistence (hyperdb.py:769-1005)
+    def _data_dict(self):
+        return {"vectors": [v.tolist() for v in self.vectors], "documents": self.documents,
+                "source_indices": self.source_indices, "split_info": getattr(self, "split_info", {}),
+                "metadata_index": getattr(self, "_metadata_index", {}),
+                "vectors_normalized": getattr(self, "vectors_normalized", False)}
+
+    def save(self, storage_file, format='pickle', save_ann_index=True):
+        """Write the database in the reference's own layout (hyperdb.py:769-899): a dict with the keys ``vectors``
+        (list of lists), ``documents``, ``source_indices``, ``split_info``, ``metadata_index``, ``vectors_normalized`` as
+        pickle (gzip when the name ends in .gz), json, or the sqlite tables of ``_save_sqlite``.  There is no ANN index
+        to save (``save_ann_index`` is accepted and ignored)."""
+        if self.vectors is None or len(self.vectors) == 0 or not self.documents:
+            print("Nothing to save. Exit.")
+            return
+        data = self._data_dict()
+        if format == 'pickle':
+            opener = gzip.open if str(storage_file).endswith(".gz") else open
+            with opener(storage_file, "wb") as f:
+                pickle.dump(data, f)
+        elif format == 'json':
+            with open(storage_file, "w") as f:
+                json.dump(data, f)
+        elif format == 'sqlite':
+            with closing(sqlite3.connect(storage_file)) as conn:
+                cur = conn.cursor()
+                cur.execute('CREATE TABLE IF NOT EXISTS documents (id INTEGER PRIMARY KEY, data TEXT)')
+                cur.execute('CREATE TABLE IF NOT EXISTS vectors (id INTEGER PRIMARY KEY, document_id INTEGER, vector BLOB)')
+                cur.execute('CREATE TABLE IF NOT EXISTS source_indices (id INTEGER PRIMARY KEY, value INTEGER)')
+                cur.execute('CREATE TABLE IF NOT EXISTS split_info (id INTEGER PRIMARY KEY, value TEXT)')
+                cur.execute('CREATE TABLE IF NOT EXISTS metadata_index (key TEXT PRIMARY KEY, value TEXT)')
+                cur.execute('CREATE TABLE IF NOT EXISTS settings (name TEXT PRIMARY KEY, value TEXT)')
+                cur.executemany('INSERT INTO documents (data) VALUES (?)', [(json.dumps(d),) for d in data["documents"]])
+                first = cur.lastrowid - len(data["documents"]) + 1
+                cur.executemany('INSERT INTO vectors (document_id, vector) VALUES (?, ?)',
+                                [(first + i, json.dumps(v)) for i, v in enumerate(data["vectors"])])
+                cur.executemany('INSERT INTO source_indices (value) VALUES (?)', [(int(i),) for i in data["source_indices"]])
+                cur.execute('INSERT INTO split_info (value) VALUES (?)', (json.dumps(data["split_info"]),))
+                cur.executemany('INSERT INTO metadata_index (key, value) VALUES (?, ?)',
+                                [(k, json.dumps(v)) for k, v in data["metadata_index"].items()])
+                cur.execute('INSERT OR REPLACE INTO settings (name, value) VALUES (?, ?)',
+                            ('vectors_normalized', json.dumps(data["vectors_normalized"])))
+                conn.commit()
+        else:
+            raise ValueError(f"Unsupported format '{format}'")
+
+    def load(self, storage_file, format='pickle', load_ann_index=True, preload_ann_into_memory=False):
+        """Read a database file written by the reference (or by ``save``) and put its matrix in HBM in ``fp_precision``
+        (hyperdb.py:901-1005).  Only load pickles you trust.  The ``.ann`` side file, if any, is not used (exact search)."""
+        if format == 'pickle':
+            try:
+                with gzip.open(storage_file, "rb") as f:
+                    data = pickle.load(f)
+            except OSError:
+                with open(storage_file, "rb") as f:
+                    data = pickle.load(f)
+        elif format == 'json':
+            with open(storage_file, "r") as f:
+                data = json.load(f)
+        elif format == 'sqlite':
+            with closing(sqlite3.connect(storage_file)) as conn:
+                cur = conn.cursor()
+                data = {"documents": [json.loads(r[0]) for r in cur.execute('SELECT data FROM documents')],
+                        "vectors": [json.loads(r[0]) for r in cur.execute('SELECT vector FROM vectors ORDER BY document_id')],
+                        "source_indices": [r[0] for r in cur.execute('SELECT value FROM source_indices')],
+                        "split_info": {}, "metadata_index": {}, "vectors_normalized": False}
+                for r in cur.execute('SELECT value FROM split_info'):
+                    data["split_info"] = json.loads(r[0])
+                for r in cur.execute('SELECT key, value FROM metadata_index'):
+                    data["metadata_index"][r[0]] = json.loads(r[1])
+                for r in cur.execute('SELECT value FROM settings WHERE name = ?', ('vectors_normalized',)):
+                    data["vectors_normalized"] = json.loads(r[0])
+        else:
+            raise ValueError(f"Unsupported format '{format}'")
+        vectors = np.array(data["vectors"], dtype=self.fp_precision)
+        if self._index is not None:
+            self._index.close()
+        self._index, self._chunks, self._host_cache = None, [], None
+        self.documents, self.source_indices = [], []
+        self.clear_cache()
+        documents = list(data["documents"])
+        if len(documents):
+            self.add(documents, vectors)
+            stored = list(data.get("source_indices", []))
+            if len(stored) == len(documents):
+                self.source_indices = stored
+        self.split_info = data.get("split_info", {})
+        self._metadata_index = data.get("metadata_index", {})
+        self.vectors_normalized = data.get("vectors_normalized", False)
 
     # ---------------------------------------------------------------- query (hyperdb.py:1429-1586)
     def _execute(self, Q, top_k, return_similarities, filters, recency_bias, timestamp_key, metric):

@@ -57,7 +57,59 @@ def test_host_helpers_without_gpu():
     with pytest.raises(Exception):
         db._row_mask([("skip_doc", 6)])
     with pytest.raises(NotImplementedError):
-        db._row_mask([("sentence", "x")])
+        db._row_mask([("key", "name")])
+    with pytest.raises(ValueError):
+        db._row_mask([("colour", "x")])
+
+
+def test_sentence_filter_semantics():
+    """Whole-word, punctuation-blind, case-blind, all tokens in ONE string, all filters must hit
+    (reference hyperdb.py:1136-1176)."""
+    from hyperdb import HyperDB
+    db = HyperDB()
+    db.documents = [{"name": "Pikachu", "info": {"description": "An electric mouse; it stores electricity!"}},
+                    {"name": "Raichu", "info": {"description": "Its tail discharges ELECTRICITY into the ground.", "tags": ["mouse", "electric"]}},
+                    "a plain string document about electricity",
+                    {"name": "Bulbasaur", "info": {"description": "A strange seed was planted on its back."}},
+                    42]
+    assert db._row_mask([("sentence", "electricity")]).tolist() == [True, True, True, False, False]
+    assert db._row_mask([("sentence", "Electric mouse")]).tolist() == [True, False, False, False, False]   # both words in one string
+    assert db._row_mask([("sentence", ["electricity", "tail"])]).tolist() == [False, True, False, False, False]
+    assert db._row_mask([("sentence", "electric")]).tolist() == [True, True, False, False, False]          # whole words only
+    assert db._row_mask([("sentence", "seed, planted!")]).tolist() == [False, False, False, True, False]
+    assert HyperDB.tokenize("Hello, World! hello") == {"hello", "world"}
+
+
+def test_save_formats_are_the_reference_layout(tmp_path):
+    """save() writes what reference load() reads (hyperdb.py:901-1005): checked on the files themselves, no GPU."""
+    import gzip, json, pickle, sqlite3
+    from hyperdb import HyperDB
+    db = HyperDB(fp_precision="float32")
+    db.documents = _docs(4)
+    db.source_indices = [0, 1, 2, 3]
+    db._chunks = [np.arange(12, dtype=np.float32).reshape(4, 3)]
+    for name in ("db.pickle", "db.pickle.gz"):
+        db.save(str(tmp_path / name))
+        opener = gzip.open if name.endswith(".gz") else open
+        with opener(tmp_path / name, "rb") as f:
+            data = pickle.load(f)
+        assert sorted(data) == ["documents", "metadata_index", "source_indices", "split_info", "vectors", "vectors_normalized"]
+        assert data["vectors"] == [[0.0, 1.0, 2.0], [3.0, 4.0, 5.0], [6.0, 7.0, 8.0], [9.0, 10.0, 11.0]]
+        assert data["documents"] == db.documents and data["source_indices"] == [0, 1, 2, 3]
+    db.save(str(tmp_path / "db.json"), format="json")
+    assert json.load(open(tmp_path / "db.json"))["vectors"][3] == [9.0, 10.0, 11.0]
+    db.save(str(tmp_path / "db.sqlite"), format="sqlite")
+    con = sqlite3.connect(tmp_path / "db.sqlite")
+    assert [json.loads(r[0]) for r in con.execute("SELECT data FROM documents")] == db.documents
+    assert [json.loads(r[0]) for r in con.execute("SELECT vector FROM vectors ORDER BY document_id")][1] == [3.0, 4.0, 5.0]
+    assert [r[0] for r in con.execute("SELECT value FROM source_indices")] == [0, 1, 2, 3]
+    assert json.loads(con.execute("SELECT value FROM settings WHERE name='vectors_normalized'").fetchone()[0]) is False
+    con.close()
+    with pytest.raises(ValueError):
+        db.save(str(tmp_path / "x"), format="xml")
+    empty = HyperDB()
+    empty.save(str(tmp_path / "nothing.pickle"))
+    assert not (tmp_path / "nothing.pickle").exists()
 
 
 # ------------------------------------------------------------------------------------------------ GPU
@@ -130,3 +182,34 @@ def test_add_remove_and_batch():
     assert db.size() == 19_999
     again = db.query(Q[0], top_k=1, metric="dot_product")
     assert again[0][0] != f"d{best}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt,name", [("pickle", "db.pickle.gz"), ("pickle", "db.pickle"), ("json", "db.json"), ("sqlite", "db.sqlite")])
+def test_save_load_round_trip_and_sentence_filter(tmp_path, fmt, name):
+    """A database written in the reference's layout comes back into HBM and answers like the original; the sentence
+    filter restricts the rows on the device."""
+    from hyperdb import HyperDB
+    rng = np.random.default_rng(7)
+    n, d = 300, 64
+    V = rng.standard_normal((n, d)).astype(np.float32)
+    docs = [{"name": f"doc{i}", "text": ("electric mouse" if i % 10 == 0 else "grass seed") + f" number {i}",
+             "timestamp": 1.7e9 + i} for i in range(n)]
+    db = HyperDB(documents=docs, vectors=V, metadata_keys=["timestamp"])
+    q = V[40] + 0.01 * rng.standard_normal(d).astype(np.float32)
+    want = db.query(q, top_k=7, metric="euclidean_metric")
+    path = str(tmp_path / name)
+    db.save(path, format=fmt)
+    db2 = HyperDB(fp_precision="float32", metadata_keys=["timestamp"])
+    db2.load(path, format=fmt)
+    assert db2.size() == n and db2.vectors.dtype == np.float32 and np.array_equal(db2.vectors, V)
+    got = db2.query(q, top_k=7, metric="euclidean_metric")
+    assert [r[0]["name"] for r in got] == [r[0]["name"] for r in want]
+    assert np.allclose([r[1] for r in got], [r[1] for r in want], atol=1e-6)
+    assert [r[2] for r in got] == [r[2] for r in want]
+    hits = db2.query(q, top_k=50, filters=[("sentence", "electric mouse")])
+    assert len(hits) == 30 and all(r[0]["text"].startswith("electric mouse") for r in hits)
+    assert hits[0][0]["name"] == "doc40"
+    half = HyperDB(fp_precision="float16")
+    half.load(path, format=fmt)                                    # lands in HBM in the requested precision
+    assert half.vectors.dtype == np.float16 and half.query(q.astype(np.float16), top_k=1)[0][0]["name"] == "doc40"
