@@ -109,6 +109,43 @@ class HyperDB:
         else:
             self._index.append(vectors)
 
+    def add_document(self, document, vectors=None, count=1, add_timestamp=False):
+        """One document and its vector (hyperdb.py:568-626); the chunked-text form (count > 1) belongs to the
+        embedding pipeline and is not built."""
+        if count != 1:
+            raise NotImplementedError("count > 1 (several chunk vectors per document) needs the text pipeline")
+        self.add([document], vectors, add_timestamp)
+
+    def add_documents(self, documents, vectors=None, add_timestamp=False):
+        """Several documents with one vector each (hyperdb.py:628-689)."""
+        self.add(list(documents), vectors, add_timestamp)
+
+    def commit_pending(self):
+        """The reference batches additions until this call (hyperdb.py:496-546); here every add is already in HBM."""
+        return None
+
+    def dict(self, vectors=False, metadata=None):
+        """The documents (optionally with their vectors under ``"vector"``), optionally restricted by a metadata
+        ``{key: value}`` dict or ``(key, value)`` tuple (hyperdb.py:444-494)."""
+        if not self.documents:
+            return []
+        keep = np.ones(len(self.documents), dtype=bool)
+        if metadata:
+            if isinstance(metadata, tuple) and len(metadata) == 2:
+                metadata = {metadata[0]: metadata[1]}
+            if not isinstance(metadata, dict):
+                raise ValueError("metadata must be a dictionary of {key: value} pairs or a tuple of (key, value).")
+            keep = self._row_mask([("metadata", metadata)])
+        host = self.vectors if vectors else None
+        out = []
+        for i, doc in enumerate(self.documents):
+            if not keep[i]:
+                continue
+            if host is not None and isinstance(doc, dict):
+                doc["vector"] = host[i].tolist()           # in place, like the reference (:487)
+            out.append(doc)
+        return out
+
     def remove_document(self, index):
         """Drop rows by index or list of indices (hyperdb.py:691-766, matrix part): the surviving rows are
         compacted on the device (one pass at HBM speed) and the row caches rebuilt; nothing is re-uploaded."""

@@ -62,6 +62,25 @@ def test_host_helpers_without_gpu():
         db._row_mask([("colour", "x")])
 
 
+def test_dict_and_aliases_without_gpu():
+    from hyperdb import HyperDB
+    db = HyperDB(metadata_keys=["info.type"])
+    db.documents = _docs(5)
+    db.source_indices = list(range(5))
+    db._chunks = [np.arange(10, dtype=np.float32).reshape(5, 2)]
+    assert [d["name"] for d in db.dict()] == [f"doc{i}" for i in range(5)]
+    odd = db.dict(metadata=("info.type", "odd"))
+    assert [d["name"] for d in odd] == ["doc1", "doc3"]
+    with_vec = db.dict(vectors=True, metadata={"info.type": "even"})
+    assert [d["vector"] for d in with_vec] == [[0.0, 1.0], [4.0, 5.0], [8.0, 9.0]]
+    with pytest.raises(ValueError):
+        db.dict(metadata=["info.type"])
+    assert db.commit_pending() is None
+    with pytest.raises(NotImplementedError):
+        db.add_document({"name": "x"}, vectors=np.ones((2, 2)), count=2)
+    assert HyperDB().dict() == []
+
+
 def test_sentence_filter_semantics():
     """Whole-word, punctuation-blind, case-blind, all tokens in ONE string, all filters must hit
     (reference hyperdb.py:1136-1176)."""
