@@ -175,7 +175,11 @@ class HyperDB:
             self._chunks = [self._host_cache]
         return self._host_cache
 
-    def size(self):
+    def size(self, with_chunks=False, metadata=None):
+        """Number of documents, optionally only those matching a metadata filter (hyperdb.py:410-442); one vector per
+        document here, so ``with_chunks`` changes nothing."""
+        if metadata:
+            return len(self.dict(metadata=metadata))
         return len(self.documents)
 
     # ---------------------------------------------------------------- LRU cache (hyperdb.py:1368-1427)
