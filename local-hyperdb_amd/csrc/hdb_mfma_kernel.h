@@ -9,6 +9,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define HDB_MFMA_CB 1024            // LDS candidate list entries per workgroup
+// Measurement builds only (tools/knockout_q256.py; the product is built with 0): 1 = survivors are never appended,
+// 2 = no LDS-DMA once the ring is primed (stale but random tiles), 4 = no per-tile barrier.  Results are wrong by design.
+#ifndef HDB_MFMA_KNOCKOUT
+#define HDB_MFMA_KNOCKOUT 0
+#endif
 
 #define HDB_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define HDB_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -158,6 +163,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
     // non-temporal (V is read once per pass by exactly one CU: +2-3 % on the HBM-bound shapes), plus the
     // per-row aux values (B waves only).  Only the last tile of the matrix can be ragged.
     auto issue = [&](int64_t t, int st) {
+        if ((HDB_MFMA_KNOCKOUT & 2) && t >= (int64_t)blockIdx.x + 3 * gstep) return;
         const int64_t row0 = hdb_tile_index(t, tstride) * R;
         const int64_t last = n_rows - 1 - row0;          // >= 0
         char* sdst = smem + st * STAGE;
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
         for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
             for (int g = 0; g < NGRP; ++g) m = fmaxf(m, gm[rt][g]);
-        if (m >= thr_cmp) {
+        if ((HDB_MFMA_KNOCKOUT & 1) ? (m == 1.2345e30f) : (m >= thr_cmp)) {
 #pragma unroll
             for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
         const bool chk = MODE == 1 && (i & chk_mask) == chk_mask;
         const int chk_slot = 1 + (int)((i >> chk_shift) & 1);
         if (chk && tid == 0) ctl[chk_slot] = (ctl[0] >= HDB_MFMA_CB / 4) ? 1u : 0u;
-        hdb_lds_barrier();                                   // tile i is in LDS; everyone is done with tile i-1
+        if (!(HDB_MFMA_KNOCKOUT & 4)) hdb_lds_barrier();     // tile i is in LDS; everyone is done with tile i-1
         // Stage the whole next-but-one tile right after the barrier, into the buffer tile i-1 used (measured:
         // 5.4-5.7 TB/s on the HBM-bound shapes vs 4.7-5.0 with the pieces spread between the MFMAs).
         const bool more = i + 2 < my_tiles;
