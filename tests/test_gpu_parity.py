@@ -635,6 +635,32 @@ def test_mfma_query_magnitude(orc, metric, scale):
         ix.close()
 
 
+def test_mfma_degenerate_queries(ranking, orc):
+    """All-zero query (every score ties at 0 -> candidate overflow -> exact selection -> the first k rows), a query
+    far below fp16's range and one with a single huge element, on an fp16 matrix through the MFMA scan.  (A query of fp32
+    subnormals is left out: its squared norm underflows to 0 in float32 -- in numpy as here -- so it ranks as unnormalised.)"""
+    rng = np.random.default_rng(123)
+    n, d, k = 30_000, 256, 25
+    V = rng.standard_normal((n, d)).astype(np.float32).astype(np.float16)
+    h = ranking.register_vectors(V)
+    try:
+        idx, sc = ranking.hyperDB_ranking_algorithm_sort(h, np.zeros(d, np.float32), top_k=k, metric="cosine_similarity")
+        assert list(idx) == list(range(k)) and np.all(sc == 0.0)
+        idx, sc = ranking.hyperDB_ranking_algorithm_sort(h, np.zeros(d, np.float32), top_k=k, metric="dot_product")
+        assert list(idx) == list(range(k)) and np.all(sc == 0.0)
+        tiny = (rng.standard_normal(d) * 1e-17).astype(np.float32)            # far below fp16's range, ||q||^2 still a normal fp32
+        idx, sc = ranking.hyperDB_ranking_algorithm_sort(h, tiny.copy(), top_k=k, metric="cosine_similarity")
+        orc.check_topk(idx, sc, V, tiny.astype(np.float64), "cosine_similarity", k, tol=2e-3)
+        spike = rng.standard_normal(d).astype(np.float32)
+        spike[7] = 1.0e15                                                       # (1e30 would overflow ||q||^2 in float32, in numpy too)
+        idx, sc = ranking.hyperDB_ranking_algorithm_sort(h, spike.copy(), top_k=k, metric="cosine_similarity")
+        assert np.isfinite(sc).all()
+        want = np.argsort(-V[:, 7].astype(np.float64) / np.linalg.norm(V.astype(np.float64), axis=1), kind="stable")[:k]
+        assert set(idx.tolist()) == set(want.tolist())                        # the spike decides: cos ~ v_7 / ||v||
+    finally:
+        h.close()
+
+
 @pytest.mark.parametrize("metric,k", [("cosine_similarity", 5000), ("hamming_distance", 3000), ("dot_product", 60_000)])
 def test_large_k_full_sort_path(ranking, orc, metric, k):
     """k above HDB_MAX_K on a matrix larger than the candidate list: all-scores + stable radix sort."""
