@@ -1,4 +1,4 @@
-"""Row-sharded index over torch.distributed with the gloo backend, world_size 2, on CPU.
+"""Row-sharded index over torch.distributed with the gloo backend, world_size 2 and 8, on CPU.
 
 What is under test is the HOST logic of hyperdb/sharded.py: shard bounds, the packed exchange record
 ([idx int64 | score f32 | status i32]), ONE all-gather per batch, merge ordering, global row ids, and
@@ -121,6 +121,28 @@ def test_two_rank_gloo_matches_global(tmp_path, metric_id, fail_rank):
     # a failed threshold on ONE rank triggers the exact re-run on BOTH (collective consistency)
     expect_exact = 1 if fail_rank is not None else 0
     assert int(r0["exact_calls"]) == expect_exact and int(r1["exact_calls"]) == expect_exact
+
+
+def test_eight_rank_gloo_matches_global(tmp_path):
+    """The node-sized case (8 ranks, uneven granule-aligned shards, a failed threshold on rank 5) on CPU."""
+    from oracle import ranking_oracle as orc
+    from hyperdb.sharded import shard_bounds
+    world, n, d, k, metric_id, fail_rank = 8, 1000, 24, 10, 1, 5
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, n, d, k, metric_id, fail_rank, str(tmp_path)), nprocs=world, join=True)
+    rng = np.random.default_rng(77)
+    V = rng.standard_normal((n, d)).astype(np.float32)
+    V[n // 2 + 3] = V[5]
+    Q = rng.standard_normal((4, d)).astype(np.float32)
+    ranks = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    assert [(int(r["lo"]), int(r["hi"])) for r in ranks] == shard_bounds(n, world, granule=16)
+    for r in ranks[1:]:
+        assert np.array_equal(r["idx"], ranks[0]["idx"]) and np.array_equal(r["sc"], ranks[0]["sc"]), "ranks must agree"
+        assert int(r["exact_calls"]) == 1                    # one rank's failed threshold -> every rank re-runs
+    for qi in range(4):
+        ex = orc.exact_scores(V, Q[qi], METRICS[metric_id]).astype(np.float32)
+        want = np.lexsort((np.arange(n), -ex))[:k]
+        assert np.array_equal(ranks[0]["idx"][qi], want) and np.array_equal(ranks[0]["sc"][qi], ex[want])
 
 
 def test_shard_bounds_cover_everything():
