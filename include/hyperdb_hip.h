@@ -87,6 +87,14 @@ int hdb_index_update(hdb_index* ix, const void* dev_V, int64_t n, void* stream);
 int hdb_index_rebase(hdb_index* ix, const void* dev_V);
 int hdb_index_extend(hdb_index* ix, int64_t new_n, void* stream);
 
+/* Compaction after HyperDB.remove_document (hyperdb.py:691-766; the reference rebuilds self.vectors on the host with
+ * np.vstack / a boolean mask, :721-728): the m kept rows dev_rows[0..m) (ascending local row ids, int64, device) are
+ * gathered into dev_V_out (m x d, caller-owned, must not alias the current matrix) in one pass at HBM speed, and the
+ * 1/||v||, ||v||^2 and NaN caches travel with their rows -- nothing is recomputed.  On return (the call synchronises
+ * `stream`) the index borrows dev_V_out with n = m and the caller may release the old matrix; bias and mask are
+ * cleared, sign-bit / pearson caches are rebuilt lazily. */
+int hdb_index_gather(hdb_index* ix, const int64_t* dev_rows, int64_t m, void* dev_V_out, void* stream);
+
 void hdb_index_destroy(hdb_index* ix);
 
 /* 1 if the matrix contains a NaN (synchronises `stream` of the create/update call). */

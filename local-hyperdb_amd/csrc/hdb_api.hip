@@ -29,12 +29,12 @@ int hdb_launch_hamming(const ScanArgs* args, int mode, int nq_launch, const uint
 int hdb_launch_hist(const float* scores, int64_t n, int64_t ld, int nq, uint32_t* hist, int pass, uint32_t k, void* stream);
 int hdb_launch_thr(const uint32_t* hist, int nq, int npass, uint32_t m, uint32_t sample_n, float* thr, uint32_t* cnt, void* stream);
 int hdb_launch_fill_thr(float* thr, uint32_t* cnt, int nq, float v, void* stream);
-void hdb_set_finalize_threads(int t);
 int hdb_launch_sample_thr(const float* scores, int64_t n, int64_t ld, int nq, uint32_t m, float* thr, uint32_t* cnt, void* stream);
 int hdb_launch_collect(const float* scores, int64_t n, int64_t ld, int nq, const uint32_t* hist, int npass, uint32_t k, uint32_t* cnt,
                        unsigned long long* cand, uint32_t cap, uint32_t* tie_info, void* stream);
 int hdb_launch_finalize(const unsigned long long* cand, const uint32_t* cnt, uint32_t cap, int nq, uint32_t k, uint32_t kk,
-                        int64_t row_base, int64_t* idx_out, float* score_out, int32_t* status, const int* qnan, void* stream);
+                        int64_t row_base, int64_t* idx_out, float* score_out, int32_t* status, const int* qnan, int threads, void* stream);
+int hdb_launch_status_nan(const int* qnan, int nq, int32_t* status, void* stream);
 int hdb_launch_merge(const void* idx_base, int64_t idx_stride, const void* score_base, int64_t score_stride,
                      const void* status_base, int64_t status_stride, int parts, int nq, uint32_t k, int64_t* idx_out,
                      float* score_out, int32_t* status_out, void* stream);
@@ -44,13 +44,14 @@ int hdb_launch_recency(const double* ts, int64_t n, double rb, double ts_max, fl
 int hdb_launch_maskbias(const uint8_t* mask, const float* bias, int64_t n, float* out, void* stream);
 int hdb_mfma_supported(int dtype, int d, int metric);
 int hdb_mfma_tile_rows(int dtype, int d);
-void hdb_set_mfma_variant(int v);
 int hdb_launch_mfma_scan(const ScanArgs* args, int dtype, int mode, int nq_launch, const void* q16, const float* sqnorm,
-                         const float* qsq, const float* qscl, int max_blocks, void* stream);
+                         const float* qsq, const float* qscl, int max_blocks, int variant, void* stream);
 int hdb_launch_q_to_f16(const float* Q, int nq, int d, void* q16, float* qscl, void* stream);
 int hdb_sort_temp_bytes(int64_t n, size_t* bytes);
 int hdb_launch_full_sort(const float* scores, int64_t n, int64_t k, int64_t row_base, uint32_t* work, void* temp, size_t temp_bytes,
                          int64_t* idx_out, float* score_out, void* stream);
+int hdb_launch_gather_rows(const void* V, const int64_t* rows, int64_t m, int row_bytes, void* out, const float* inv_in,
+                           const float* sq_in, float* inv_out, float* sq_out, int* nan_flag, void* stream);
 int hdb_launch_rescore_euclid(unsigned long long* cand, const uint32_t* cnt, uint32_t cap, int nq_launch, const void* V, int dtype, int d,
                               const float* Q, const float* qsq, int q0, const float* bias, void* stream);
 }
@@ -112,6 +113,8 @@ struct hdb_index {
     int64_t exact_bytes = (int64_t)1 << 30;
     int64_t bits_fused = 1;           // hamming / jaccard: try the sampled-threshold path first (exact path when it fails)
     int64_t host_direct = 1;          // hdb_topk_host: kernels write a pinned host record themselves (no D2H copy)
+    int64_t finalize_threads = 1024;  // workgroup size of hdb_finalize_kernel (256 | 512 | 1024)
+    int64_t mfma_variant = 16;        // MFMA shape of the d=384 256-query pass (16 | 32)
     // stats of the last hdb_topk call
     int64_t st_sample_rows = 0, st_sample_m = 0, st_path = 0, st_chunks = 0, st_mfma = 0, st_host_direct = 0;
     // optional HIP-event timing of the dominant kernel (the pass over all of V)
@@ -230,6 +233,32 @@ extern "C" int hdb_index_extend(hdb_index* ix, int64_t new_n, void* stream) {
     return HDB_OK;
 }
 
+extern "C" int hdb_index_gather(hdb_index* ix, const int64_t* dev_rows, int64_t m, void* dev_V_out, void* stream) {
+    if (!ix) return fail(HDB_ERR_ARG, "hdb_index_gather: null index");
+    if (m < 0 || m > ix->n) return fail(HDB_ERR_ARG, "hdb_index_gather: m must be in [0, n]");
+    if (m > 0 && (!dev_rows || !dev_V_out)) return fail(HDB_ERR_ARG, "hdb_index_gather: null argument");
+    if (m > 0 && dev_V_out == ix->V) return fail(HDB_ERR_ARG, "hdb_index_gather: the gather is out of place");
+    HIP_TRY(hipSetDevice(ix->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t elem = ix->dtype == HDB_F16 ? 2 : ix->dtype == HDB_F32 ? 4 : 8;
+    float *inv2 = nullptr, *sq2 = nullptr;
+    const int64_t rows = m + m / 4 + 64;
+    HIP_TRY(hipMalloc((void**)&inv2, rows * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&sq2, rows * sizeof(float)));
+    HIP_TRY(hipMemsetAsync(ix->nan_flag, 0, sizeof(int), st));
+    int rc = hdb_launch_gather_rows(ix->V, dev_rows, m, (int)(ix->d * elem), dev_V_out, ix->inv_norm, ix->sqnorm, inv2, sq2,
+                                    ix->nan_flag, st);
+    if (rc == 0) rc = (int)hipStreamSynchronize(st);          // the old caches (and the caller's old matrix) are free after this
+    if (rc != 0) { (void)hipFree(inv2); (void)hipFree(sq2); return fail(HDB_ERR_HIP, std::string("hdb_index_gather: ") + hipGetErrorString((hipError_t)rc)); }
+    if (ix->inv_norm) { (void)hipFree(ix->inv_norm); (void)hipFree(ix->sqnorm); }
+    ix->inv_norm = inv2; ix->sqnorm = sq2; ix->cache_rows = rows;
+    ix->V = dev_V_out; ix->n = m;
+    ix->bits_valid = false; ix->pscale_valid = false;
+    ix->bias = nullptr; ix->mask = nullptr;
+    ix->build_stream = st;
+    return HDB_OK;
+}
+
 extern "C" void hdb_index_destroy(hdb_index* ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
@@ -276,8 +305,8 @@ extern "C" int hdb_set_option(hdb_index* ix, const char* name, int64_t value) {
     else if (!strcmp(name, "mfma_min_q")) ix->mfma_min_q = value;
     else if (!strcmp(name, "use_mfma")) ix->use_mfma = value;
     else if (!strcmp(name, "exact_bytes")) ix->exact_bytes = std::max<int64_t>(1 << 20, value);
-    else if (!strcmp(name, "finalize_threads")) hdb_set_finalize_threads((int)value);
-    else if (!strcmp(name, "mfma_variant")) hdb_set_mfma_variant((int)value);
+    else if (!strcmp(name, "finalize_threads")) { if (value == 256 || value == 512 || value == 1024) ix->finalize_threads = value; }
+    else if (!strcmp(name, "mfma_variant")) { if (value == 16 || value == 32) ix->mfma_variant = value; }
     else if (!strcmp(name, "host_direct")) ix->host_direct = value;
     else if (!strcmp(name, "bits_fused")) ix->bits_fused = value;
     else if (!strcmp(name, "profile")) { ix->profile = value; ix->ev_used = 0; }
@@ -374,7 +403,7 @@ static int run_scan(hdb_index* ix, ScanArgs& a, int mode, int cq, const QueryBuf
     if (is_bits_metric(a.metric)) {
         LAUNCH_TRY(hdb_launch_hamming(&a, mode, cq, ix->bits, ix->bits_npad, ix->W, qb.qbits, st));
     } else if (mfma) {
-        LAUNCH_TRY(hdb_launch_mfma_scan(&a, ix->dtype, mode, cq, qb.q16, ix->sqnorm, qb.qsq, qb.qscl, (int)ix->max_blocks, st));
+        LAUNCH_TRY(hdb_launch_mfma_scan(&a, ix->dtype, mode, cq, qb.q16, ix->sqnorm, qb.qsq, qb.qscl, (int)ix->max_blocks, (int)ix->mfma_variant, st));
     } else {
         LAUNCH_TRY(hdb_launch_scan(&a, ix->dtype, mode, cq, (int)ix->max_blocks, st));
     }
@@ -450,8 +479,6 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
         if (dev_status) HIP_TRY(hipMemsetAsync(dev_status, 0, (size_t)nq * sizeof(int32_t), st));
         return HDB_OK;
     }
-    if ((size_t)std::min<int64_t>(k, HDB_CAND_CAP) > HDB_CAND_CAP) return fail(HDB_ERR_ARG, "hdb_topk: k too large");
-
     const bool small = n <= HDB_CAND_CAP;
     const bool is_ham = is_bits_metric(metric);
     const bool is_pearson = metric == HDB_PEARSON;
@@ -545,7 +572,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
             LAUNCH_TRY(hdb_launch_full_sort(sc1, n, k, ix->row_base, work, temp, tb, dev_idx + (int64_t)q0 * k,
                                             dev_score + (int64_t)q0 * k, st));
         }
-        if (dev_status) HIP_TRY(hipMemsetAsync(dev_status, 0, (size_t)nq * sizeof(int32_t), st));
+        if (dev_status) LAUNCH_TRY(hdb_launch_status_nan(qnan2, nq, dev_status, st));     // HDB_Q_NAN survives on this path too
         return HDB_OK;
     }
     // the MFMA scan has no mask input: excluded rows get a bias of -inf instead (never appended, like the VALU scan)
@@ -620,7 +647,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
             LAUNCH_TRY(hdb_launch_rescore_euclid(cand, cnt, HDB_CAND_CAP, cq, ix->V, ix->dtype, ix->d, (const float*)dev_Q, qsq, q0, ix->bias, st));
         LAUNCH_TRY(hdb_launch_finalize(cand, cnt, HDB_CAND_CAP, cq, (uint32_t)k, kk, ix->row_base,
                                        dev_idx + (int64_t)q0 * k, dev_score + (int64_t)q0 * k,
-                                       dev_status ? dev_status + q0 : nullptr, qnan + q0, st));
+                                       dev_status ? dev_status + q0 : nullptr, qnan + q0, (int)ix->finalize_threads, st));
     }
     return HDB_OK;
 }

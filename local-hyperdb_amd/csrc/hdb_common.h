@@ -117,6 +117,33 @@ __device__ __forceinline__ A hdb_rows4_sum(A a0, A a1, A a2, A a3, int l16) {
 __device__ __forceinline__ int hdb_owned_row(int l16) { return ((l16 >> 2) & 1) * 2 + ((l16 >> 3) & 1); }
 
 // ---- launch helpers (host) -------------------------------------------------------------------
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per device: `done` holds one bit per device ordinal (the
+// static word lives in each kernel instantiation's launcher), so a second GPU in the process sets it again.
+static inline hipError_t hdb_lds_attr_once(const void* fn, int bytes, unsigned long long* done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (*done & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) *done |= bit;
+    return e;
+}
+
+// Compute units of the current device (256 on MI355X), cached per device ordinal: persistent kernels launch one
+// workgroup per CU.
+static inline int hdb_cu_count() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    int& c = cached[dev & 63];
+    if (c <= 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        c = v;
+    }
+    return c;
+}
 static inline int hdb_grid_for(int64_t work_items, int per_block, int max_blocks) {
     int64_t b = (work_items + per_block - 1) / per_block;
     if (b < 1) b = 1;

@@ -100,8 +100,7 @@ extern "C" int hdb_mfma_supported(int dtype, int d, int metric) {
 // d=384, more than 128 queries: 16 = 16x16x32 with two query tiles per wave (default: the same FLOPs and LDS
 // traffic as the 32x32x16 form, but the chip holds a higher clock on this shape: 1.78-1.85 ms against 2.07-2.25 ms
 // for N=10M, Q=256), 32 = 32x32x16 with one query tile per wave (kept for A/B measurements).
-static int g_mfma_variant = 16;
-extern "C" void hdb_set_mfma_variant(int v) { if (v == 16 || v == 32) g_mfma_variant = v; }
+// (per index: hdb_set_option(ix, "mfma_variant", 16 | 32), passed down as `variant`)
 
 extern "C" int hdb_mfma_qt2_supported(int d);
 extern "C" int hdb_launch_mfma_scan_f16_qt2(const ScanArgs* args, int mode, int nq_launch, const void* q16, const float* sqnorm,
@@ -112,11 +111,13 @@ extern "C" int hdb_launch_mfma_scan_f32(const ScanArgs* args, int mode, int nq_l
 // a.ntiles / a.tile_stride are in units of hdb_mfma_tile_rows(dtype, d) rows here.  q: the query fragments' source --
 // scaled fp16 copies (+ qscl) for fp16 matrices, the float32 queries themselves (qscl = nullptr) for fp32 ones.
 extern "C" int hdb_launch_mfma_scan(const ScanArgs* args, int dtype, int mode, int nq_launch, const void* q16, const float* sqnorm,
-                                    const float* qsq, const float* qscl, int max_blocks, void* stream) {
+                                    const float* qsq, const float* qscl, int max_blocks, int variant, void* stream) {
+    const int g_mfma_variant = variant == 32 ? 32 : 16;
     const ScanArgs& a = *args;
     hipStream_t st = (hipStream_t)stream;
     if (a.mask) return (int)hipErrorNotSupported;
-    int blocks = (int)(a.ntiles < 256 ? a.ntiles : 256);
+    const int cus = hdb_cu_count();                      // one persistent workgroup per CU
+    int blocks = (int)(a.ntiles < cus ? a.ntiles : cus);
     if (max_blocks > 0 && max_blocks < blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
     if (dtype == HDB_F32) return hdb_launch_mfma_scan_f32(args, mode, nq_launch, q16, sqnorm, qsq, blocks, stream);
@@ -157,3 +158,11 @@ extern "C" int hdb_launch_rescore_euclid(unsigned long long* cand, const uint32_
     }
     return (int)hipGetLastError();
 }
+
+#if HDB_MFMA_CLOCK
+// Diagnostic build only: copy the stamps of the last launch of THIS translation unit's kernels (d = 384 lives here).
+extern "C" int hdb_debug_read_clock(unsigned long long* host_out, int wgs) {
+    if (wgs > HDB_CLOCK_WGS) wgs = HDB_CLOCK_WGS;
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(hdb_clock_buf), (size_t)wgs * 4 * sizeof(unsigned long long));
+}
+#endif

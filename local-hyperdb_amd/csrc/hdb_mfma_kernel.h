@@ -15,6 +15,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define HDB_MFMA_KNOCKOUT 0
 #endif
 
+// Diagnostic build only (tools/clock_q256.py; the product is built with 0): stamp s_memtime (shader clock) and
+// s_memrealtime (constant 100 MHz) around the tile loop; lane 0 of wave 0 of every workgroup stores the four stamps
+// into a buffer of their own that no kernel reads (MI355X_MICROARCH.md, DVFS give-back item 6).  The in-kernel clock
+// is d(memtime) / d(memrealtime) x 100 MHz.
+#ifndef HDB_MFMA_CLOCK
+#define HDB_MFMA_CLOCK 0
+#endif
+#if HDB_MFMA_CLOCK
+#define HDB_CLOCK_WGS 1024
+static __device__ unsigned long long hdb_clock_buf[4 * HDB_CLOCK_WGS];
+#endif
+
 #define HDB_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define HDB_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
@@ -285,6 +297,10 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
 
     const int chk_shift = ntiles >= 65536 ? 4 : 0;
     const int64_t chk_mask = (1 << chk_shift) - 1;
+#if HDB_MFMA_CLOCK
+    const unsigned long long clk_c0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0) alone: keeps the loop's counted LDS waits as written
+#endif
     Acc acc[QT][RT];
     int64_t row0_prev = 0;
     int st_cur = 0;
@@ -431,6 +447,16 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
         if (more && heavy && grpB) issue(t_cur + 2 * gstep, st_next2);      // B's half of the staging, after its MFMA phase
         st_cur = st_cur == 2 ? 0 : st_cur + 1;
     }
+#if HDB_MFMA_CLOCK
+    {
+        const unsigned long long clk_c1 = __builtin_amdgcn_s_memtime(), clk_r1 = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (tid == 0 && blockIdx.y == 0 && blockIdx.x < HDB_CLOCK_WGS) {
+            unsigned long long* o = hdb_clock_buf + 4 * blockIdx.x;
+            o[0] = clk_c0; o[1] = clk_c1; o[2] = clk_r0; o[3] = clk_r1;
+        }
+    }
+#endif
     if (MODE == 1) {
         if (wave_active && grpB && my_tiles > 0) filter(acc, row0_prev);
         flush();
@@ -446,12 +472,9 @@ template <typename E, int MF, int QT, int D, int R, int RS, int MODE, int METRIC
 static int launch_one(const ScanArgs& a, const void* q16, const float* aux0, const float* qsq, const float* qscl, int nq_launch, int blocks, hipStream_t st) {
     auto kern = hdb_mfma_kernel<E, MF, QT, D, R, RS, MODE, METRIC, HAS_BIAS>;
     const size_t lds = mfma_lds_bytes(R * D * (int)sizeof(E));
-    static bool attr_done = false;          // per instantiation
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static unsigned long long attr_done = 0;          // per instantiation, one bit per device
+    hipError_t e = hdb_lds_attr_once(reinterpret_cast<const void*>(kern), (int)lds, &attr_done);
+    if (e != hipSuccess) return (int)e;
     const dim3 grid(blocks, (nq_launch + (8 / RS) * MF * QT - 1) / ((8 / RS) * MF * QT));
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a, (const E*)q16, aux0, qsq, qscl, a.q0 + nq_launch);
     return (int)hipGetLastError();

@@ -480,19 +480,24 @@ extern "C" int hdb_launch_collect(const float* scores, int64_t n, int64_t ld, in
     hipLaunchKernelGGL(hdb_ties_seq_kernel, dim3(nq), dim3(1024), 0, (hipStream_t)stream, scores, n, ld, cnt, cand, cap, tie_info);
     return (int)hipGetLastError();
 }
-static int g_finalize_threads = 1024;
-extern "C" void hdb_set_finalize_threads(int t) { if (t == 256 || t == 512 || t == 1024) g_finalize_threads = t; }
+// status[q] = HDB_Q_NAN if the query held a NaN, else 0 (the full-sort path has no finalize kernel to write it)
+__global__ void hdb_status_nan_kernel(const int* qnan, int nq, int32_t* status) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nq) status[i] = qnan[i] ? HDB_Q_NAN : 0;
+}
+extern "C" int hdb_launch_status_nan(const int* qnan, int nq, int32_t* status, void* stream) {
+    hipLaunchKernelGGL(hdb_status_nan_kernel, dim3((nq + 255) / 256), dim3(256), 0, (hipStream_t)stream, qnan, nq, status);
+    return (int)hipGetLastError();
+}
 extern "C" int hdb_launch_finalize(const unsigned long long* cand, const uint32_t* cnt, uint32_t cap, int nq, uint32_t k,
                                    uint32_t kk, int64_t row_base, int64_t* idx_out, float* score_out, int32_t* status,
-                                   const int* qnan, void* stream) {
+                                   const int* qnan, int threads, void* stream) {
     const size_t lds = (size_t)cap * 16 + 2048 * 4 + 64;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hdb_finalize_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(hdb_finalize_kernel, dim3(nq), dim3(g_finalize_threads), lds, (hipStream_t)stream, cand, cnt, cap, k, kk,
+    static unsigned long long attr_done = 0;
+    hipError_t e = hdb_lds_attr_once(reinterpret_cast<const void*>(hdb_finalize_kernel), (int)lds, &attr_done);
+    if (e != hipSuccess) return (int)e;
+    if (threads != 256 && threads != 512) threads = 1024;
+    hipLaunchKernelGGL(hdb_finalize_kernel, dim3(nq), dim3(threads), lds, (hipStream_t)stream, cand, cnt, cap, k, kk,
                        row_base, idx_out, score_out, status, qnan);
     return (int)hipGetLastError();
 }

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+from collections import OrderedDict
 
 import numpy as np
 import torch  # must be imported before the .so so that ONE libamdhip64 (torch's) serves both
@@ -33,7 +34,7 @@ NAN_MESSAGE = "Vectors and query_vector should not contain NaN values."   # refe
 
 EXPORTS = (
     "hdb_version", "hdb_last_error", "hdb_index_create", "hdb_index_update", "hdb_index_rebase", "hdb_index_extend",
-    "hdb_index_destroy",
+    "hdb_index_gather", "hdb_index_destroy",
     "hdb_index_has_nan", "hdb_index_set_bias", "hdb_index_set_row_mask", "hdb_scores", "hdb_topk",
     "hdb_topk_exact", "hdb_merge_topk", "hdb_set_option", "hdb_get_stat", "hdb_recency_bias",
     "hdb_packed_bytes", "hdb_merge_topk_packed", "hdb_topk_host",
@@ -58,6 +59,7 @@ def _load():
     lib.hdb_index_update.argtypes = [vp, vp, i64, vp]
     lib.hdb_index_rebase.argtypes = [vp, vp]
     lib.hdb_index_extend.argtypes = [vp, i64, vp]
+    lib.hdb_index_gather.argtypes = [vp, vp, i64, vp, vp]
     lib.hdb_index_destroy.argtypes = [vp]
     lib.hdb_index_destroy.restype = None
     lib.hdb_index_has_nan.argtypes = [vp, ctypes.POINTER(ctypes.c_int)]
@@ -158,6 +160,8 @@ class GpuIndex:
         self._bias = None
         self._mask = None
         self._nan = None
+        self._buf = None
+        self._host_records = OrderedDict()     # (nq, k) -> pinned record + views, owned by THIS index (small LRU)
         with torch.cuda.device(self.device):
             _check(_lib.hdb_index_create(ctypes.byref(self._h), ctypes.c_void_p(t.data_ptr()), self.n, self.d,
                                          self.dtype, self.device.index or 0, self.row_base,
@@ -168,6 +172,9 @@ class GpuIndex:
         if getattr(self, "_h", None) is not None and self._h.value:
             _lib.hdb_index_destroy(self._h)
             self._h = ctypes.c_void_p()
+        if getattr(self, "_host_records", None):
+            self._host_records.clear()                 # releases the pinned host memory
+        self._buf = None
 
     def __del__(self):
         try:
@@ -188,7 +195,7 @@ class GpuIndex:
         m = int(t.shape[0])
         if m == 0:
             return
-        buf = getattr(self, "_buf", None)
+        buf = self._buf
         if buf is None or buf.data_ptr() != self.V.data_ptr():
             buf = self.V                                    # first append: the registered tensor is the buffer
         cap = int(buf.shape[0])
@@ -213,8 +220,22 @@ class GpuIndex:
             raise ValueError("update: matrix must keep d and dtype")
         self.V, self.n = t, int(t.shape[0])
         self._bias = self._mask = self._nan = None
+        self._buf = None                                    # the old capacity buffer is released with the old matrix
         _check(_lib.hdb_index_update(self._h, ctypes.c_void_p(t.data_ptr()), self.n, _stream_ptr(self.device)),
                "hdb_index_update")
+
+    def compact(self, keep_rows):
+        """Keep only the rows `keep_rows` (ascending local row ids): device-side gather into a fresh allocation, the
+        row caches travel with their rows (hdb_index_gather) -- the matrix part of HyperDB.remove_document
+        (hyperdb.py:691-766) without a host round trip or a cache rebuild."""
+        rows = torch.from_numpy(np.ascontiguousarray(np.asarray(keep_rows, dtype=np.int64))).to(self.device)
+        m = int(rows.numel())
+        out = torch.empty((max(m, 1), self.d), dtype=self.V.dtype, device=self.device)
+        _check(_lib.hdb_index_gather(self._h, ctypes.c_void_p(rows.data_ptr()), m, ctypes.c_void_p(out.data_ptr()),
+                                     _stream_ptr(self.device)), "hdb_index_gather")
+        self._buf = out
+        self.V, self.n = out[:m], m
+        self._bias = self._mask = self._nan = None
 
     @property
     def has_nan(self):
@@ -240,23 +261,32 @@ class GpuIndex:
         self._bias = b
         _check(_lib.hdb_index_set_bias(self._h, ctypes.c_void_p(b.data_ptr())), "hdb_index_set_bias")
 
-    def set_recency(self, timestamps, recency_bias):
+    def set_recency(self, timestamps, recency_bias, ts_max=None, valid=None):
         """bias = recency_bias * exp(ts - max ts) (reference ranking_algorithm.py:183), computed on the
-        device in float64 from float64 timestamps, stored as float32."""
+        device in float64 from float64 timestamps, stored as float32.
+
+        ts_max: the maximum to normalise by when it is not the maximum of `timestamps` itself -- the GLOBAL maximum of
+        a row-sharded matrix (ShardedIndex.set_recency all-reduces it), or the maximum over the rows that take part
+        when a row mask is set.  valid: optional boolean array; the maximum is then taken over those rows only (the
+        reference ranks the FILTERED rows, hyperdb.py:1556, so rows a filter removed must not move the maximum)."""
         if timestamps is None or len(timestamps) == 0:
             self.set_bias(None)
             return
         if isinstance(timestamps, torch.Tensor):
             ts = timestamps.to(self.device, torch.float64).contiguous()
-            ts_max = float(ts.max().item())
+            if ts_max is None:
+                sel = ts if valid is None else ts[torch.as_tensor(np.asarray(valid, dtype=bool), device=self.device)]
+                ts_max = float(sel.max().item()) if sel.numel() else 0.0
         else:
             ts_h = np.ascontiguousarray(np.asarray(timestamps, dtype=np.float64))
-            ts_max = float(np.max(ts_h))
+            if ts_max is None:
+                sel = ts_h if valid is None else ts_h[np.asarray(valid, dtype=bool)]
+                ts_max = float(np.max(sel)) if sel.size else 0.0
             ts = torch.from_numpy(ts_h).to(self.device)
         if ts.numel() != self.n:
             raise ValueError(f"operands could not be broadcast together with shapes ({self.n},) ({ts.numel()},)")
         out = torch.empty(self.n, dtype=torch.float32, device=self.device)
-        _check(_lib.hdb_recency_bias(ctypes.c_void_p(ts.data_ptr()), self.n, float(recency_bias), ts_max,
+        _check(_lib.hdb_recency_bias(ctypes.c_void_p(ts.data_ptr()), self.n, float(recency_bias), float(ts_max),
                                      ctypes.c_void_p(out.data_ptr()), self.device.index or 0,
                                      _stream_ptr(self.device)), "hdb_recency_bias")
         self._bias = out
@@ -342,16 +372,21 @@ class GpuIndex:
     def topk_views(self, Q, k, metric_id):
         """One C call (hdb_topk_host): kernels + D2H of the packed record into a cached pinned buffer + sync + the
         rare exact re-run.  Returns numpy VIEWS (idx int64 [nq,k], score float32 [nq,k], status int32 [nq]) that are
-        overwritten by the next call with the same (nq, k)."""
+        overwritten by the next call of THIS index with the same (nq, k); the record belongs to the index (two
+        indices, devices or shard groups never share one) and at most HOST_RECORD_SLOTS shapes are kept."""
         qt = self._query_tensor(Q, batched=True)
         nq, k = int(qt.shape[0]), int(k)
-        slot = _host_records.get((nq, k))
+        slot = self._host_records.get((nq, k))
         if slot is None:                                 # pinned record + its numpy views, built once per (nq, k)
             host = torch.empty(packed_bytes(nq, k), dtype=torch.uint8, pin_memory=True)
             h = host.numpy()
             slot = (host, ctypes.c_void_p(host.data_ptr()), h[:nq * k * 8].view(np.int64).reshape(nq, k),
                     h[nq * k * 8:nq * k * 12].view(np.float32).reshape(nq, k), h[nq * k * 12:nq * k * 12 + nq * 4].view(np.int32))
-            _host_records[(nq, k)] = slot
+            self._host_records[(nq, k)] = slot
+            while len(self._host_records) > HOST_RECORD_SLOTS:
+                self._host_records.popitem(last=False)
+        else:
+            self._host_records.move_to_end((nq, k))
         _check(_lib.hdb_topk_host(self._h, ctypes.c_void_p(qt.data_ptr()), nq, k, int(metric_id), slot[1],
                                   _stream_ptr(self.device)), "hdb_topk_host")
         return slot[2], slot[3], slot[4]
@@ -368,19 +403,22 @@ def packed_bytes(nq, k):
     return int(_lib.hdb_packed_bytes(int(nq), int(k)))
 
 
-_pinned = {}
-_host_records = {}          # (nq, k) -> (pinned tensor, its pointer, idx / score / status views) for GpuIndex.topk_views
+HOST_RECORD_SLOTS = 8      # pinned result records kept per index / per staging owner (LRU)
 
 
-def record_to_host(record, nq, k):
-    """ONE D2H copy of a packed record (pinned staging buffer, cached per size) -> numpy views
-    (idx int64 [nq,k], score float32 [nq,k], status int32 [nq]).  Views alias the staging buffer:
-    callers copy what they keep."""
+def record_to_host(record, nq, k, cache):
+    """ONE D2H copy of a packed record (pinned staging buffer from `cache`, an OrderedDict owned by the caller and
+    keyed by size) -> numpy views (idx int64 [nq,k], score float32 [nq,k], status int32 [nq]).  Views alias the
+    staging buffer: callers copy what they keep."""
     nb = record.numel()
-    host = _pinned.get(nb)
+    host = cache.get(nb)
     if host is None:
         host = torch.empty(nb, dtype=torch.uint8, pin_memory=True)
-        _pinned[nb] = host
+        cache[nb] = host
+        while len(cache) > HOST_RECORD_SLOTS:
+            cache.popitem(last=False)
+    else:
+        cache.move_to_end(nb)
     host.copy_(record, non_blocking=True)
     torch.cuda.current_stream(record.device).synchronize()
     h = host.numpy()

@@ -3,10 +3,14 @@
 Scope: ONLY what sits either side of the hot path -- the constructor that
 takes documents + precomputed vectors, ``query()`` with the reference's signature and return shapes,
 and the ~30 lines of ``_execute_query`` around the ranking call (hyperdb.py:1461-1469, :1541-1575).
-Also here, from the "next" rows of SURVEY.md section 8f: ``save`` / ``load`` in the reference's own pickle, json and
-sqlite layouts (hyperdb.py:769-1005) so an existing database file goes straight into HBM, and the ``sentence``
-filter (a host predicate).  Everything else the reference class does (sentence-transformer embedding, Annoy, the
-``key`` filter that re-embeds sub-documents) is out of scope and is NOT re-implemented here.
+Also here, from the "next" rows of SURVEY.md section 8f: ``load`` (and its inverse ``save``) in the reference's own
+pickle, json and sqlite layouts (hyperdb.py:769-1005) so an existing database file goes straight into HBM.  Everything
+else the reference class does (sentence-transformer embedding, Annoy, the text filters ``key`` and ``sentence``) is out
+of scope and is NOT re-implemented here; a caller that has its own text predicate passes its result as a ``mask`` filter.
+
+Matrix residency: the N x d matrix lives ONLY in HBM (there is no host mirror; ``.vectors`` copies it back on demand).
+``remove_document`` tombstones the rows (O(1) on the device: they join every query's row mask) and compacts the matrix
+on the device, caches included, once a quarter of the rows are dead (``GpuIndex.compact`` -> hdb_index_gather).
 
 Differences from the reference, all deliberate:
   * the N x d matrix is registered once on the GPU (``GpuIndex``) -- no per-query NaN scan, copy or
@@ -16,9 +20,9 @@ Differences from the reference, all deliberate:
     O(N) Python index rebuild on every add/remove (hyperdb.py:218-220);
   * ranked rows map to documents by row id, O(k), instead of ``self.documents.index(document)``
     (hyperdb.py:1568, O(N) dict comparisons per hit);
-  * ``filters``: ``skip_doc``, ``metadata`` equality and ``sentence`` (whole-word, hyperdb.py:1136-1176) filters
-    become a device row mask; the ``key`` filter re-embeds sub-documents (hyperdb.py:1087) and raises
-    NotImplementedError without a model;
+  * ``filters``: ``skip_doc`` and ``metadata`` equality become a device row mask, and so does the additive
+    ``("mask", bool_array)`` filter; ``key`` (re-embeds sub-documents, hyperdb.py:1087) and ``sentence`` (text search,
+    hyperdb.py:1136-1176) belong to the text pipeline and raise NotImplementedError;
   * strings can be queried only when an ``embedding_function`` is supplied (no model download).
 Kept from the reference: argument names and defaults, metric whitelist and messages, the top_k warning,
 ``(document, score, source_index)`` / ``document`` return shapes, the LRU result cache, and the DOUBLE
@@ -27,12 +31,11 @@ ranking_algorithm.py:183).
 """
 from __future__ import annotations
 
+import datetime
 import gzip
 import json
 import pickle
-import re
 import sqlite3
-import string
 from collections import OrderedDict
 from contextlib import closing
 
@@ -60,16 +63,19 @@ class HyperDB:
         self.select_keys = [select_keys] if isinstance(select_keys, str) else select_keys
         self.metadata_keys = [metadata_keys] if isinstance(metadata_keys, str) else (metadata_keys or [])
         self.add_timestamp = add_timestamp
+        if self.add_timestamp and "timestamp" not in self.metadata_keys:      # hyperdb.py:104-107
+            self.metadata_keys.append("timestamp")
         self.ann_metric, self.n_trees = ann_metric, n_trees          # accepted for compatibility; no ANN is built
         self.device = device
         self.documents, self.source_indices = [], []
-        self._chunks, self._host_cache = [], None
         self._index = None
+        self._dead = np.zeros(0, dtype=np.int64)     # tombstoned device rows (ascending); see remove_document
+        self._ts_cache = {}                           # timestamp_key -> float64 array over documents (NaN = missing)
         self._cache = OrderedDict()
         self._cache_size = cache_size
         self.cache_hits = self.cache_misses = 0
         if documents is not None or vectors is not None:
-            self.add(documents, vectors)
+            self.add(documents, vectors, add_timestamp=self.add_timestamp)
 
     # ---------------------------------------------------------------- matrix lifecycle (hyperdb.py:496-766)
     def _embed(self, documents):
@@ -78,7 +84,7 @@ class HyperDB:
                              "(pass vectors=... or an embedding_function).")
         return np.asarray(self.embedding_function(documents))
 
-    def add(self, documents, vectors=None, add_timestamp=None):
+    def add(self, documents, vectors=None, add_timestamp=False):
         """Append documents with their vectors (hyperdb.py:548-566 without chunking/embedding).
 
         The device matrix grows in place (capacity doubling) and only the new rows' caches are computed:
@@ -98,11 +104,15 @@ class HyperDB:
         if self._index is not None and vectors.shape[1] != self._index.d:
             raise ValueError("All vectors must have the same dimension, one per document.")
         vectors = vectors.astype(self.fp_precision, copy=False)
+        if add_timestamp:                                   # hyperdb.py:582-588: dict documents get metadata.timestamp
+            now = float(datetime.datetime.now().timestamp())
+            for doc in documents:
+                if isinstance(doc, dict):
+                    doc.setdefault('metadata', {})['timestamp'] = now
         start = len(self.documents)
         self.documents = list(self.documents) + list(documents)
         self.source_indices = list(self.source_indices) + list(range(start, start + len(documents)))
-        self._chunks.append(vectors)
-        self._host_cache = None
+        self._ts_cache.clear()
         self.clear_cache()
         if self._index is None:
             self._index = GpuIndex(vectors, device=self.device)
@@ -146,34 +156,61 @@ class HyperDB:
             out.append(doc)
         return out
 
+    # device row of every live document (identity while nothing is tombstoned)
+    def _live_rows(self):
+        if self._index is None:
+            return np.zeros(0, dtype=np.int64)
+        if self._dead.size == 0:
+            return np.arange(self._index.n, dtype=np.int64)
+        alive = np.ones(self._index.n, dtype=bool)
+        alive[self._dead] = False
+        return np.flatnonzero(alive)
+
+    def _docs_of_rows(self, rows):
+        """device rows -> positions in self.documents: every tombstone below a row shifts it down by one."""
+        rows = np.asarray(rows, dtype=np.int64)
+        return rows if self._dead.size == 0 else rows - np.searchsorted(self._dead, rows)
+
     def remove_document(self, index):
-        """Drop rows by index or list of indices (hyperdb.py:691-766, matrix part): the surviving rows are
-        compacted on the device (one pass at HBM speed) and the row caches rebuilt; nothing is re-uploaded."""
-        import torch
-        drop = np.atleast_1d(np.asarray(index, dtype=np.int64))
-        keep = np.ones(len(self.documents), dtype=bool)
-        keep[drop] = False
-        self.documents = [d for d, k in zip(self.documents, keep) if k]
-        self.source_indices = [s for s, k in zip(self.source_indices, keep) if k]
-        host = self.vectors
-        self._chunks = [host[keep]] if host is not None and keep.any() else []
-        self._host_cache = None
-        self.clear_cache()
+        """Drop documents by index or list of indices (hyperdb.py:691-766, one vector per document).
+
+        Host lists shrink like the reference's (source_indices renumbered to stay consecutive, :737-745).  The device
+        rows are only tombstoned -- they join the row mask of every query, O(1) on the GPU -- until a quarter of the
+        stored rows are dead; then the matrix is compacted on the device with its row caches (hdb_index_gather): one
+        pass at HBM speed, nothing re-uploaded, no cache rebuilt.  The reference re-stacks the host array on every
+        removal (:721-728) and re-normalises all rows on the next query."""
+        n_docs = len(self.documents)
+        drop = sorted({int(i) % n_docs if -n_docs <= int(i) < 0 else int(i) for i in np.atleast_1d(np.asarray(index)).tolist()})
+        if drop and (drop[0] < 0 or drop[-1] >= n_docs):
+            raise IndexError("pop index out of range")                  # what self.documents.pop(idx) raises (:717)
+        if not drop:
+            return
+        gone = set(drop)
         if self._index is not None:
-            if not keep.any():
-                self._index.close()
-                self._index = None
-            else:
-                kept = self._index.V[torch.from_numpy(keep).to(self._index.device)]
-                self._index.update(kept)
+            self._dead = np.union1d(self._dead, self._live_rows()[np.asarray(drop, dtype=np.int64)])
+        self.documents = [d for i, d in enumerate(self.documents) if i not in gone]
+        kept_src = [s_ for s_ in self.source_indices if s_ not in gone]     # :737-745
+        drop_arr = np.asarray(drop)
+        self.source_indices = [int(s_ - np.searchsorted(drop_arr, s_)) for s_ in kept_src]
+        self._ts_cache.clear()
+        self.clear_cache()
+        if self._index is None:
+            return
+        if not self.documents:
+            self._index.close()
+            self._index, self._dead = None, np.zeros(0, dtype=np.int64)
+        elif self._dead.size * 4 > self._index.n:
+            self._index.compact(self._live_rows())
+            self._dead = np.zeros(0, dtype=np.int64)
 
     @property
     def vectors(self):
-        """Host copy of the matrix (what the reference keeps in self.vectors); concatenated lazily."""
-        if self._host_cache is None and self._chunks:
-            self._host_cache = self._chunks[0] if len(self._chunks) == 1 else np.concatenate(self._chunks, axis=0)
-            self._chunks = [self._host_cache]
-        return self._host_cache
+        """The stored matrix as a host array, copied back from HBM on demand (the reference keeps it in self.vectors;
+        here the only resident copy is the device one)."""
+        if self._index is None:
+            return None
+        host = self._index.V.cpu().numpy()
+        return host if self._dead.size == 0 else host[self._live_rows()]
 
     def size(self, with_chunks=False, metadata=None):
         """Number of documents, optionally only those matching a metadata filter (hyperdb.py:410-442); one vector per
@@ -215,19 +252,31 @@ class HyperDB:
                 return None
         return value
 
-    def _handle_timestamps(self, recency_bias, timestamp_key, documents):
-        """First application of the decay: rb * exp(ts - max ts) (hyperdb.py:1310-1346)."""
+    def _timestamps(self, timestamp_key):
+        """float64 timestamps of all documents under ``timestamp_key`` (NaN where missing), extracted once per key and
+        reused until the document list changes (the reference walks every document on every query, hyperdb.py:1333-1334)."""
+        ts = self._ts_cache.get(timestamp_key)
+        if ts is None:
+            nested = timestamp_key.split('.') if '.' in timestamp_key else [timestamp_key]
+            vals = [self.get_nested_value(doc, nested) for doc in self.documents]
+            ts = np.array([np.nan if v is None else v for v in vals], dtype=float)
+            self._ts_cache[timestamp_key] = ts
+        return ts
+
+    def _handle_timestamps(self, recency_bias, timestamp_key, keep=None):
+        """First application of the decay over the FILTERED documents: rb * exp(ts - max ts) (hyperdb.py:1310-1346,
+        called with filtered_documents at :1555).  Returns one value per kept document, or None."""
         if recency_bias == 0:
             return None
         if timestamp_key is None:
             timestamp_key = "timestamp"
         if timestamp_key not in self.metadata_keys:
             raise ValueError(f"The timestamp_key '{timestamp_key}' must be present in metadata_keys when recency_bias is not 0.")
-        nested = timestamp_key.split('.') if '.' in timestamp_key else [timestamp_key]
-        ts = [self.get_nested_value(doc, nested) for doc in documents]
-        if None in ts:
+        ts = self._timestamps(timestamp_key)
+        if keep is not None:
+            ts = ts[keep]
+        if np.isnan(ts).any():
             raise ValueError("All timestamps must be populated when recency_bias is not 0 or timestamp_key is provided.")
-        ts = np.array(ts, dtype=float)
         return recency_bias * np.exp(-np.max(ts) + ts)
 
     def _query_vectors(self, query_input):
@@ -252,7 +301,8 @@ class HyperDB:
         return q
 
     def _row_mask(self, filters):
-        """skip_doc (hyperdb.py:1119-1134) and metadata equality filters -> boolean row mask, or None."""
+        """skip_doc (hyperdb.py:1119-1134), metadata equality and caller-supplied ``mask`` filters -> boolean array
+        over self.documents, or None."""
         if not filters:
             return None
         n = len(self.documents)
@@ -271,36 +321,20 @@ class HyperDB:
                     nested = key.split('.')
                     keep &= np.array([self.get_nested_value(doc, nested) == want if isinstance(doc, dict) else False
                                       for doc in self.documents])
+            elif name == 'mask':                                                # additive: the caller's own predicate
+                m = np.asarray(params, dtype=bool).reshape(-1)
+                if m.size != n:
+                    raise ValueError(f"mask filter needs one boolean per document ({n}), got {m.size}")
+                keep &= m
             elif name == 'sentence':
-                wanted = params if isinstance(params, (list, tuple)) else [params]
-                token_sets = [self.tokenize(w) for w in wanted]              # each filter tokenised once (:1164-1165)
-                keep &= np.array([all(self.recursive_sentence_filter(doc, ts) for ts in token_sets) for doc in self.documents],
-                                 dtype=bool)
+                raise NotImplementedError("filter 'sentence' is a text search (hyperdb.py:1136-1176): out of scope here; "
+                                          "evaluate the predicate on the host and pass ('mask', bool_array) instead")
             elif name == 'key':
                 raise NotImplementedError("filter 'key' re-embeds sub-documents (hyperdb.py:1087): needs the embedding "
                                           "pipeline, which is out of scope here")
             else:
                 raise ValueError(f"Invalid filter name {name}")                # hyperdb.py:1279-1280
         return keep
-
-    # ---------------------------------------------------------------- sentence filter (hyperdb.py:1136-1176)
-    @staticmethod
-    def tokenize(text):
-        """Lower-cased word set of a string with punctuation removed (hyperdb.py:1136-1141)."""
-        text = ''.join(c for c in text if c not in string.punctuation)
-        return set(re.findall(r'\b\w+\b', text.lower()))
-
-    @classmethod
-    def recursive_sentence_filter(cls, obj, sentence_filter_tokens):
-        """True when some string inside ``obj`` (dicts and lists are searched recursively) contains every token
-        as a whole word (hyperdb.py:1143-1158)."""
-        if isinstance(obj, dict):
-            return any(cls.recursive_sentence_filter(v, sentence_filter_tokens) for v in obj.values())
-        if isinstance(obj, list):
-            return any(cls.recursive_sentence_filter(v, sentence_filter_tokens) for v in obj)
-        if isinstance(obj, str):
-            return sentence_filter_tokens.issubset(cls.tokenize(obj))
-        return False
 
     # ---------------------------------------------------------------- persistence (hyperdb.py:769-1005)
     def _data_dict(self):
@@ -379,8 +413,9 @@ class HyperDB:
         vectors = np.array(data["vectors"], dtype=self.fp_precision)
         if self._index is not None:
             self._index.close()
-        self._index, self._chunks, self._host_cache = None, [], None
+        self._index, self._dead = None, np.zeros(0, dtype=np.int64)
         self.documents, self.source_indices = [], []
+        self._ts_cache.clear()
         self.clear_cache()
         documents = list(data["documents"])
         if len(documents):
@@ -402,30 +437,52 @@ class HyperDB:
         ix = self._index
         if ix.has_nan or np.isnan(Q).any():
             raise ValueError(ranking.NAN_MESSAGE)
-        mask = self._row_mask(filters)
-        n_avail = len(self.documents) if mask is None else int(mask.sum())
+        keep = self._row_mask(filters)                          # over documents
+        n_avail = len(self.documents) if keep is None else int(keep.sum())
         if n_avail == 0:
             print("INFO: No document matches your query with the brute-force method and the current filters.")
             return [[] for _ in range(len(Q))]
         if top_k > n_avail:
             print(f"Warning: top_k ({top_k}) is greater than the number of filtered documents ({n_avail}). Setting top_k to {n_avail}.")
             top_k = n_avail
-        first = self._handle_timestamps(recency_bias, timestamp_key, self.documents)     # decay #1 (host, float64)
+        # decay #1 (host, float64) over the documents the filters kept, like hyperdb.py:1555
+        first = self._handle_timestamps(recency_bias, timestamp_key, keep)
+        # documents -> device rows: filters and tombstones become ONE row mask
+        row_mask = None
+        rows_kept = None
+        if keep is not None or self._dead.size:
+            live = self._live_rows()
+            rows_kept = live if keep is None else live[keep]
+            row_mask = np.zeros(ix.n, dtype=bool)
+            row_mask[rows_kept] = True
         try:
-            ix.set_row_mask(mask)
+            ix.set_row_mask(row_mask)
             if first is not None:
-                ix.set_recency(first, recency_bias)                                     # decay #2, ranking_algorithm.py:183
+                # decay #2, ranking_algorithm.py:183: rb * exp(first - max(first)) with the maximum over the kept rows
+                # only (the reference ranks the filtered rows); masked rows get the neutral exp(0) and are never returned
+                fmax = float(np.max(first))
+                if rows_kept is None:
+                    first_rows = first
+                else:
+                    first_rows = np.full(ix.n, fmax, dtype=np.float64)
+                    first_rows[rows_kept] = first
+                ix.set_recency(first_rows, recency_bias, ts_max=fmax)
             idx, sc = ix.topk(Q, int(top_k), METRIC_IDS[metric])
         finally:
             ix.set_row_mask(None)
             ix.set_bias(None)
+        if n_avail == 1:
+            print("Info: Only one document left.")                               # ranking_algorithm.py:189-191
         out = []
         for qi in range(len(Q)):
-            rows = idx[qi]
+            rows = idx[qi][idx[qi] >= 0]
+            docs = self._docs_of_rows(rows)
+            # one row left: the reference's scores come back 2-D (:191), so scores[i] is a 1-element array
+            val = (lambda s_: np.array([float(s_)])) if n_avail == 1 else float
             if return_similarities:
-                out.append([(self.documents[r], float(sc[qi][j]), self.source_indices[r]) for j, r in enumerate(rows) if r >= 0])
+                out.append([(self.documents[r], val(sc[qi][j]), self.source_indices[r]) for j, r in enumerate(docs)])
             else:
-                out.append([self.documents[r] for r in rows if r >= 0])
+                out.append([self.documents[r] for r in docs])
         return out
 
     def query(self, query_input, top_k=5, return_similarities=True, filters=None, recency_bias=0, timestamp_key=None,

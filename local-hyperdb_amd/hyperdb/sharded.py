@@ -17,6 +17,8 @@ with the gloo backend on CPU in tests; the product engine is the HIP one and not
 """
 from __future__ import annotations
 
+from collections import OrderedDict
+
 import numpy as np
 import torch
 
@@ -33,7 +35,7 @@ class HipEngine:
         self.index = index
         self.device = index.device
         self._records = {}
-        self._host = {}
+        self._host = OrderedDict()        # pinned staging records of THIS engine, bounded (see _native.HOST_RECORD_SLOTS)
 
     def packed_bytes(self, nq, k):
         from . import _native
@@ -56,15 +58,27 @@ class HipEngine:
 
     def record_to_host(self, record, nq, k):
         from . import _native
-        return _native.record_to_host(record, nq, k)
+        return _native.record_to_host(record, nq, k, self._host)
+
+    def set_recency(self, timestamps, recency_bias, ts_max):
+        self.index.set_recency(timestamps, recency_bias, ts_max=ts_max)
+
+    def local_ts_max(self, timestamps):
+        if timestamps is None or len(timestamps) == 0:
+            return float("-inf")
+        if isinstance(timestamps, torch.Tensor):
+            return float(timestamps.max().item())
+        return float(np.max(np.asarray(timestamps, dtype=np.float64)))
 
     def merge_packed_to_host(self, gathered, parts, nq, k):
         """Merge straight into a pinned host record (the merge kernel stores over PCIe itself: no D2H copy)."""
         from . import _native
         nb = _native.packed_bytes(nq, k)
-        host = self._host.get(nb)
+        host = self._host.get(("merge", nb))
         if host is None:
-            host = self._host[nb] = torch.empty(nb, dtype=torch.uint8, pin_memory=True)
+            host = self._host[("merge", nb)] = torch.empty(nb, dtype=torch.uint8, pin_memory=True)
+            while len(self._host) > _native.HOST_RECORD_SLOTS:
+                self._host.popitem(last=False)
         _native.merge_topk_packed_into(gathered, parts, nq, k, host)
         torch.cuda.current_stream(self.device).synchronize()
         h = host.numpy()
@@ -117,6 +131,17 @@ class ShardedIndex:
         return eng.record_to_host(merged, nq, k)
 
     # -- public --------------------------------------------------------------------------------
+    def set_recency(self, timestamps, recency_bias):
+        """Recency term of THIS rank's rows, normalised by the GLOBAL newest timestamp: bias_i = rb * exp(ts_i - max
+        over ALL shards) (reference ranking_algorithm.py:183 takes the maximum over every stored row).  One all-reduce
+        (MAX) of a scalar when the term is set -- nothing is exchanged per query.  `timestamps` = this shard's rows."""
+        ts_max = self.engine.local_ts_max(timestamps)
+        if self.world > 1:
+            t = torch.tensor([ts_max], dtype=torch.float64, device=self.engine.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            ts_max = float(t.item())
+        self.engine.set_recency(timestamps, recency_bias, ts_max)
+
     def query(self, Q, k, metric_id):
         """Global top-k of a (nq, d) query batch: (int64 [nq,k], float32 [nq,k]) numpy, same on all ranks."""
         if Q.dim() == 1:

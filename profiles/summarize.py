@@ -4,6 +4,16 @@
   python profiles/summarize.py stats gpurun_out/prof_r1 profiles/r1_bench_q1_kernel_stats.csv
   python profiles/summarize.py pmc   gpurun_out/pmc_fetch_r1 gpurun_out/pmc_write_r1 "hdb_scan_kernel<__half, 1, 1" \
          profiles/r1_bench_q1_hbm_traffic.json
+  python profiles/summarize.py mfma  "Li16ELi2ELi384" 1.966e12 profiles/r2_q256_pmc.json gpurun_out/pmc_q256_a gpurun_out/pmc_q256_b ...
+
+The mfma mode condenses one or more `rocprofv3 --pmc ...` passes (each run as `rocprofv3 --pmc <counters> -d <dir>
+--output-format csv -- python3 tools/run_q256.py`, the program directly after `--`) over the dispatches whose kernel
+name contains the needle: average of every counter, average dispatch duration (End - Start timestamp of the counter
+rows), and the derived figures bench.py reports for the batched leg:
+  clock_ghz      = GRBM_GUI_ACTIVE / 8 XCDs / duration        (MI355X_MICROARCH.md, DVFS give-back)
+  mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CU_CYCLES x 4): busy cycles of the matrix pipes over the cycles
+                   of the busy CUs' 4 SIMDs; cross-checked against the instruction count (FLOP / 16384 per
+                   v_mfma_f32_16x16x32_f16 x 16 cycles) over 1024 SIMDs x (GRBM_GUI_ACTIVE / 8).
 
 Kernel names are cut to 110 characters (torch's RNG kernels have 6 KB names).  The pmc mode applies the
 gfx950 corrections of MI355X_MICROARCH.md (HBM section): FETCH_SIZE/WRITE_SIZE are in KiB, and
@@ -52,8 +62,52 @@ def pmc(fetch_dir, write_dir, needle, dst):
     print(json.dumps(out))
 
 
+def mfma(needle, flop, dst, dirs):
+    counters, durs, regs = {}, [], {}
+    for d in dirs:
+        for path in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+            seen = set()
+            for r in csv.DictReader(open(path)):
+                if needle not in r["Kernel_Name"]:
+                    continue
+                counters.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+                if r["Dispatch_Id"] not in seen:
+                    seen.add(r["Dispatch_Id"])
+                    durs.append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+                regs = {"vgpr": r["VGPR_Count"], "agpr": r["Accum_VGPR_Count"], "sgpr": r["SGPR_Count"], "lds": r["LDS_Block_Size"],
+                        "workgroup": r["Workgroup_Size"], "grid": r["Grid_Size"]}
+    if not durs:
+        raise SystemExit(f"no dispatch matching {needle!r}")
+    avg = {k: sum(v) / len(v) for k, v in counters.items()}
+    dur_ns = sum(durs) / len(durs)
+    out = {"kernel_needle": needle, "dispatches": len(durs), "duration_us_profiled": dur_ns / 1e3, "launch": regs,
+           "counters_avg_per_dispatch": avg, "passes": dirs}
+    gui = avg.get("GRBM_GUI_ACTIVE")
+    if gui:
+        cyc = gui / 8.0
+        out["clock_ghz"] = cyc / dur_ns
+        out["clock_formula"] = "GRBM_GUI_ACTIVE / 8 / duration_ns"
+        if flop:
+            mfma_cycles = flop / 16384.0 * 16.0
+            out["mfma_busy_frac_from_flop"] = mfma_cycles / (1024.0 * cyc)
+            out["tflops_profiled"] = flop / dur_ns / 1e3
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and avg.get("SQ_BUSY_CU_CYCLES"):
+        out["mfma_busy_frac"] = avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (avg["SQ_BUSY_CU_CYCLES"] * 4.0)
+        out["mfma_busy_formula"] = "SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CU_CYCLES * 4)"
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and gui:
+        out["mfma_busy_frac_vs_gui"] = avg["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * gui / 8.0)
+    if avg.get("SQ_WAVE_CYCLES"):
+        for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY"):
+            if k in avg:
+                out[k + "_share_of_wave_cycles"] = avg[k] / avg["SQ_WAVE_CYCLES"]
+    json.dump(out, open(dst, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "mfma":
+        mfma(sys.argv[2], float(sys.argv[3]), sys.argv[4], sys.argv[5:])
     else:
         pmc(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])

@@ -13,6 +13,8 @@ Files written:
                re-run through the reference, inputs and outputs recorded;
   sweep.npz    seeded random matrices x {7 metrics} x {k} x {recency on/off}: full score
                vectors of every metric function and (indices, scores) of the sort entry;
+  c1.npz       BASELINE config 1: 151 x 384 seeded vectors (the size of demo/pokemon.jsonl with MiniLM-sized
+               embeddings), query = row 142 + noise, cosine top-5 by the reference on the CPU;
   edge.npz     N==1, top_k==0, top_k>N, zero rows, (1,d) query, ties, in-place query
                binarisation, raw-vs-double recency.
 """
@@ -187,11 +189,26 @@ def edge(ref):
     print("edge.npz:", len(cases), "cases")
 
 
+def c1(ref):
+    """BASELINE config 1 (plumbing): the reference's numpy path on a pokemon-sized store."""
+    rng = np.random.default_rng(151)
+    V = rng.standard_normal((151, 384)).astype(np.float32)
+    q = (V[142] + 0.05 * rng.standard_normal(384)).astype(np.float32)
+    (idx, sc), _ = quiet(ref.hyperDB_ranking_algorithm_sort, V.copy(), q.copy(), top_k=5, metric="cosine_similarity")
+    np.savez_compressed(os.path.join(HERE, "c1.npz"), V=V, q=q, ref_idx=np.asarray(idx), ref_scores=np.asarray(sc))
+    print("c1.npz: top-5", list(idx))
+
+
 if __name__ == "__main__":
+    import sys
     ref = load_reference()
+    if sys.argv[1:] == ["c1"]:          # only the config-1 fixture (the other files are unchanged)
+        c1(ref)
+        raise SystemExit(0)
     kat(ref)
     sweep(ref)
     edge(ref)
+    c1(ref)
     import numpy, scipy
     with open(os.path.join(HERE, "PROVENANCE.txt"), "w") as f:
         f.write("Generated by tests/golden/make_golden.py from the reference ranking module loaded by path\n"

@@ -8,6 +8,17 @@ import numpy as np
 import pytest
 
 
+def _host_db(vectors=None, **kw):
+    """HyperDB whose ``vectors`` come from a host array: lets the host-only glue (dict, save) run without a GPU."""
+    from hyperdb import HyperDB
+
+    class HostOnly(HyperDB):
+        vectors = None
+    db = HostOnly(**kw)
+    HostOnly.vectors = vectors
+    return db
+
+
 def _docs(n):
     return [{"name": f"doc{i}", "info": {"type": "even" if i % 2 == 0 else "odd", "n": i},
              "timestamp": 1.7e9 + 3600.0 * i} for i in range(n)]
@@ -45,12 +56,23 @@ def test_host_helpers_without_gpu():
     from hyperdb import HyperDB
     db = HyperDB(metadata_keys=["timestamp", "info.type"])
     db.documents = _docs(6)
-    first = db._handle_timestamps(0.5, "timestamp", db.documents)
+    first = db._handle_timestamps(0.5, "timestamp")
     ts = np.array([d["timestamp"] for d in db.documents])
     assert np.allclose(first, 0.5 * np.exp(ts - ts.max()))
-    assert db._handle_timestamps(0, None, db.documents) is None
+    # over the FILTERED documents (hyperdb.py:1555): the maximum is the newest KEPT document
+    keep = np.array([True, True, True, False, False, False])
+    assert np.allclose(db._handle_timestamps(0.5, "timestamp", keep), 0.5 * np.exp(ts[:3] - ts[2]))
+    assert db._handle_timestamps(0, None) is None
     with pytest.raises(ValueError):
-        db._handle_timestamps(0.5, "created", db.documents)
+        db._handle_timestamps(0.5, "created")
+    # a document without a timestamp only matters when it is kept
+    del db.documents[5]["timestamp"]
+    db._ts_cache.clear()
+    with pytest.raises(ValueError, match="All timestamps must be populated"):
+        db._handle_timestamps(0.5, "timestamp")
+    assert db._handle_timestamps(0.5, "timestamp", keep) is not None
+    db.documents[5]["timestamp"] = float(ts[5])
+    db._ts_cache.clear()
     m = db._row_mask([("skip_doc", 2), ("metadata", {"info.type": "even"})])
     assert m.tolist() == [False, False, True, False, True, False]
     assert db._row_mask([("skip_doc", -2)]).tolist() == [True] * 4 + [False] * 2
@@ -58,16 +80,20 @@ def test_host_helpers_without_gpu():
         db._row_mask([("skip_doc", 6)])
     with pytest.raises(NotImplementedError):
         db._row_mask([("key", "name")])
+    with pytest.raises(NotImplementedError):
+        db._row_mask([("sentence", "electric mouse")])          # text search: out of scope, callers pass a mask
+    assert db._row_mask([("mask", [1, 0, 1, 1, 0, 0]), ("skip_doc", 1)]).tolist() == [False, False, True, True, False, False]
+    with pytest.raises(ValueError):
+        db._row_mask([("mask", [True, False])])
     with pytest.raises(ValueError):
         db._row_mask([("colour", "x")])
 
 
 def test_dict_and_aliases_without_gpu():
     from hyperdb import HyperDB
-    db = HyperDB(metadata_keys=["info.type"])
+    db = _host_db(np.arange(10, dtype=np.float32).reshape(5, 2), metadata_keys=["info.type"])
     db.documents = _docs(5)
     db.source_indices = list(range(5))
-    db._chunks = [np.arange(10, dtype=np.float32).reshape(5, 2)]
     assert [d["name"] for d in db.dict()] == [f"doc{i}" for i in range(5)]
     odd = db.dict(metadata=("info.type", "odd"))
     assert [d["name"] for d in odd] == ["doc1", "doc3"]
@@ -81,32 +107,44 @@ def test_dict_and_aliases_without_gpu():
     assert HyperDB().dict() == []
 
 
-def test_sentence_filter_semantics():
-    """Whole-word, punctuation-blind, case-blind, all tokens in ONE string, all filters must hit
-    (reference hyperdb.py:1136-1176)."""
+def test_remove_document_host_bookkeeping():
+    """Host lists after remove_document follow hyperdb.py:691-766: documents popped, source_indices renumbered to
+    stay consecutive; device rows are tombstoned and row ids map back to the shifted document positions."""
     from hyperdb import HyperDB
     db = HyperDB()
-    db.documents = [{"name": "Pikachu", "info": {"description": "An electric mouse; it stores electricity!"}},
-                    {"name": "Raichu", "info": {"description": "Its tail discharges ELECTRICITY into the ground.", "tags": ["mouse", "electric"]}},
-                    "a plain string document about electricity",
-                    {"name": "Bulbasaur", "info": {"description": "A strange seed was planted on its back."}},
-                    42]
-    assert db._row_mask([("sentence", "electricity")]).tolist() == [True, True, True, False, False]
-    assert db._row_mask([("sentence", "Electric mouse")]).tolist() == [True, False, False, False, False]   # both words in one string
-    assert db._row_mask([("sentence", ["electricity", "tail"])]).tolist() == [False, True, False, False, False]
-    assert db._row_mask([("sentence", "electric")]).tolist() == [True, True, False, False, False]          # whole words only
-    assert db._row_mask([("sentence", "seed, planted!")]).tolist() == [False, False, False, True, False]
-    assert HyperDB.tokenize("Hello, World! hello") == {"hello", "world"}
+    db.documents = [f"d{i}" for i in range(8)]
+    db.source_indices = list(range(8))
+    db.remove_document([5, 2])
+    assert db.documents == ["d0", "d1", "d3", "d4", "d6", "d7"] and db.source_indices == [0, 1, 2, 3, 4, 5]
+    db.remove_document(0)
+    assert db.documents[0] == "d1" and db.source_indices == [0, 1, 2, 3, 4]
+    with pytest.raises(IndexError):
+        db.remove_document(5)
+    # tombstone arithmetic (no index attached here, so set the state by hand)
+    db._dead = np.array([0, 2, 5], dtype=np.int64)
+    assert db._docs_of_rows([1, 3, 4, 6, 7]).tolist() == [0, 1, 2, 3, 4]
+
+
+def test_add_timestamp_stamps_dict_documents():
+    """add_timestamp (hyperdb.py:104-107, :582-588): 'timestamp' joins metadata_keys, dict documents get
+    metadata.timestamp; checked on the host lists by stopping before the upload."""
+    from hyperdb import HyperDB
+    db = HyperDB(add_timestamp=True)
+    assert "timestamp" in db.metadata_keys
+    docs = [{"name": "a"}, "plain string", {"name": "b", "metadata": {"x": 1}}]
+    with pytest.raises(Exception):                        # no GPU here: the upload raises after the host part ran
+        db.add(docs, vectors=np.ones((3, 4), dtype=np.float32), add_timestamp=True)
+    assert isinstance(docs[0]["metadata"]["timestamp"], float) and docs[2]["metadata"]["x"] == 1
+    assert docs[2]["metadata"]["timestamp"] == docs[0]["metadata"]["timestamp"] and docs[1] == "plain string"
 
 
 def test_save_formats_are_the_reference_layout(tmp_path):
     """save() writes what reference load() reads (hyperdb.py:901-1005): checked on the files themselves, no GPU."""
     import gzip, json, pickle, sqlite3
     from hyperdb import HyperDB
-    db = HyperDB(fp_precision="float32")
+    db = _host_db(np.arange(12, dtype=np.float32).reshape(4, 3), fp_precision="float32")
     db.documents = _docs(4)
     db.source_indices = [0, 1, 2, 3]
-    db._chunks = [np.arange(12, dtype=np.float32).reshape(4, 3)]
     for name in ("db.pickle", "db.pickle.gz"):
         db.save(str(tmp_path / name))
         opener = gzip.open if name.endswith(".gz") else open
@@ -126,7 +164,7 @@ def test_save_formats_are_the_reference_layout(tmp_path):
     con.close()
     with pytest.raises(ValueError):
         db.save(str(tmp_path / "x"), format="xml")
-    empty = HyperDB()
+    empty = _host_db(None)
     empty.save(str(tmp_path / "nothing.pickle"))
     assert not (tmp_path / "nothing.pickle").exists()
 
@@ -198,16 +236,99 @@ def test_add_remove_and_batch():
         assert all(r[0] == f"d{r[2]}" for r in out[qi])
     best = out[0][0][2]
     db.remove_document(best)
-    assert db.size() == 19_999
+    assert db.size() == 19_999 and db._dead.tolist() == [best]          # tombstoned on the device, not moved
     again = db.query(Q[0], top_k=1, metric="dot_product")
     assert again[0][0] != f"d{best}"
+    # rows behind the tombstone map to shifted document positions; source_indices were renumbered (hyperdb.py:737-745)
+    keep = np.ones(20_000, dtype=bool)
+    keep[best] = False
+    live = np.nonzero(keep)[0]
+    oi, osc = orc.rank(V16[keep], Q[3], top_k=7, metric="dot_product")
+    got = db.query(Q[3], top_k=7, metric="dot_product")
+    assert orc.same_result_modulo_ties([r[2] for r in got], [r[1] for r in got], oi, osc, 1e-3)
+    assert all(r[0] == f"d{live[r[2]]}" for r in got)
+    # enough removals trigger the device-side compaction (hdb_index_gather): caches travel with the rows
+    gone = rng.choice(19_999, size=6_000, replace=False)
+    db.remove_document(gone.tolist())
+    assert db._dead.size == 0 and db._index.n == db.size() == 13_999
+    keep2 = np.ones(19_999, dtype=bool)
+    keep2[gone] = False
+    live2 = live[keep2]
+    assert np.array_equal(db.vectors, V16[live2])
+    for metric in ("cosine_similarity", "euclidean_metric", "hamming_distance"):
+        oi, osc = orc.rank(V16[live2], Q[4].copy(), top_k=7, metric=metric)
+        got = db.query(Q[4].copy(), top_k=7, metric=metric)
+        if metric == "hamming_distance":
+            assert [r[1] for r in got] == sorted(osc.tolist(), reverse=True)
+        else:
+            assert orc.same_result_modulo_ties([r[2] for r in got], [r[1] for r in got], oi, osc, 1e-3)
+        assert all(r[0] == f"d{live2[r[2]]}" for r in got)
+    db.add(["late"], vectors=V[:1])                                     # appending after a compaction still works
+    assert db.size() == 14_000 and db.query(V16[0], top_k=2, metric="cosine_similarity")[0][1] > 0.999
+
+
+@pytest.mark.gpu
+def test_filters_with_recency_use_the_filtered_maximum():
+    """the reference calls _handle_timestamps on the FILTERED documents (hyperdb.py:1555), so both decays are
+    normalised by the newest KEPT document, and only kept documents need a timestamp.  The newest documents are
+    filtered out here; with the global maximum exp(ts - max) would collapse to ~0 for unix timestamps."""
+    from hyperdb import HyperDB
+    from oracle import ranking_oracle as orc
+    rng = np.random.default_rng(3)
+    n, d = 400, 64
+    V = rng.standard_normal((n, d)).astype(np.float32)
+    docs = _docs(n)                                             # timestamps grow with i, one hour apart
+    del docs[399]["timestamp"]                                  # filtered out below: must not raise
+    db = HyperDB(documents=docs, vectors=V, metadata_keys=["timestamp", "info.type"], ann_metric="dot")
+    q = rng.standard_normal(d).astype(np.float32)
+    keep = np.array([i < 300 and i % 2 == 1 for i in range(n)])
+    res = db.query(q, top_k=6, recency_bias=0.8, timestamp_key="timestamp", metric="cosine_similarity",
+                   filters=[("skip_doc", -100), ("metadata", {"info.type": "odd"})])
+    ts = np.array([dd["timestamp"] for dd in np.array(docs, dtype=object)[keep]])
+    first = 0.8 * np.exp(ts - ts.max())
+    oi, osc = orc.rank(V[keep], q, top_k=6, metric="cosine_similarity", timestamps=first, recency_bias=0.8)
+    assert [r[2] for r in res] == list(np.nonzero(keep)[0][oi])
+    assert np.allclose([r[1] for r in res], osc, atol=1e-5)
+    assert max(r[1] for r in res) > 0.5                         # the recency term acts (it would be ~0 with the global max)
+    with pytest.raises(ValueError, match="All timestamps must be populated"):
+        db.query(q, top_k=6, recency_bias=0.8, timestamp_key="timestamp")          # unfiltered: document 399 counts
+    # one document left: the reference's 2-D score and its Info line (ranking_algorithm.py:189-191)
+    one = db.query(q, top_k=3, filters=[("mask", np.arange(n) == 17)], metric="dot_product")
+    assert len(one) == 1 and one[0][2] == 17 and np.shape(one[0][1]) == (1,)
+    assert np.allclose(one[0][1], V[17] @ q, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_config1_pokemon_shaped_documents(capsys):
+    """BASELINE config 1 as written: 151 documents with the schema of demo/pokemon.jsonl (name, shortname, hp,
+    info{id,type,weakness,description}, images{...}, moves[...]; values synthetic), seeded 151 x 384 vectors, cosine
+    top-5 through HyperDB.query() -- against the oracle and the committed reference output (tests/golden/c1.npz)."""
+    import os
+    from hyperdb import HyperDB
+    from oracle import ranking_oracle as orc
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "c1.npz"))
+    V, q = g["V"], g["q"]
+    types = ["psychic", "flying", "fire", "water", "grass", "electric", "rock"]
+    docs = [{"name": f"Mon{i:03d}", "shortname": f"mon{i:03d}", "hp": 100 + 10 * (i % 20),
+             "info": {"id": i + 1, "type": types[i % 7], "weakness": types[(i + 3) % 7], "description": f"Synthetic creature number {i}."},
+             "images": {"photo": f"images/mon{i:03d}.jpg", "typeIcon": f"icons/{types[i % 7]}.jpg", "weaknessIcon": f"icons/{types[(i + 3) % 7]}.jpg"},
+             "moves": [{"name": "Tackle", "dp": 40, "type": "normal"}, {"name": "Double Team", "type": "normal"}]} for i in range(151)]
+    db = HyperDB(documents=docs, vectors=V, metadata_keys=["info.type"], ann_metric="dot")   # cosine != "dot": brute force
+    res = db.query(q, top_k=5)
+    assert [r[2] for r in res] == g["ref_idx"].tolist() == orc.rank(V, q, top_k=5)[0].tolist()
+    assert np.allclose([r[1] for r in res], g["ref_scores"], atol=1e-5)
+    assert res[0][0]["info"]["id"] == 143 and res[0][0]["name"] == "Mon142"
+    fire = db.query(q, top_k=5, filters=[("metadata", {"info.type": "fire"})])
+    keep = np.array([i % 7 == 2 for i in range(151)])
+    oi, osc = orc.rank(V[keep], q, top_k=5)
+    assert [r[2] for r in fire] == list(np.nonzero(keep)[0][oi]) and all(r[0]["info"]["type"] == "fire" for r in fire)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("fmt,name", [("pickle", "db.pickle.gz"), ("pickle", "db.pickle"), ("json", "db.json"), ("sqlite", "db.sqlite")])
-def test_save_load_round_trip_and_sentence_filter(tmp_path, fmt, name):
-    """A database written in the reference's layout comes back into HBM and answers like the original; the sentence
-    filter restricts the rows on the device."""
+def test_save_load_round_trip_and_mask_filter(tmp_path, fmt, name):
+    """A database written in the reference's layout comes back into HBM and answers like the original; a caller-
+    supplied mask filter restricts the rows on the device."""
     from hyperdb import HyperDB
     rng = np.random.default_rng(7)
     n, d = 300, 64
@@ -226,7 +347,8 @@ def test_save_load_round_trip_and_sentence_filter(tmp_path, fmt, name):
     assert [r[0]["name"] for r in got] == [r[0]["name"] for r in want]
     assert np.allclose([r[1] for r in got], [r[1] for r in want], atol=1e-6)
     assert [r[2] for r in got] == [r[2] for r in want]
-    hits = db2.query(q, top_k=50, filters=[("sentence", "electric mouse")])
+    mouse = np.array([dd["text"].startswith("electric mouse") for dd in docs])      # the caller's own text predicate
+    hits = db2.query(q, top_k=50, filters=[("mask", mouse)])
     assert len(hits) == 30 and all(r[0]["text"].startswith("electric mouse") for r in hits)
     assert hits[0][0]["name"] == "doc40"
     half = HyperDB(fp_precision="float16")

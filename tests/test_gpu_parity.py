@@ -262,6 +262,30 @@ def test_config2_fp32_1m_cosine(ranking, orc):
         h.close()
 
 
+def _slices(n, count=10, rows=200_000):
+    """`count` row windows of `rows` rows spread evenly over [0, n), the first at row 0 and the last ending at n."""
+    rows = min(rows, n)
+    if count == 1 or rows == n:
+        return [(0, rows)]
+    return [(lo, lo + rows) for lo in (int(round(i * (n - rows) / (count - 1))) for i in range(count))]
+
+
+def _assert_nothing_left_out(orc, V_dev, q, metric, idx_row, sc_row, tol, bias_dev=None, count=10, rows=200_000, row_base=0):
+    """Independent omission check over the WHOLE row range: float64 scores (oracle.exact_scores, host) of `count`
+    windows spread from the first to the last row of the device matrix; any row that beats the k-th returned score by
+    more than the rounding band must be among the returned rows."""
+    n = int(V_dev.shape[0])
+    kth = float(np.min(sc_row))
+    returned = set(int(i) for i in idx_row)
+    slack = 2.0 * tol * max(1.0, abs(kth)) if tol else 0.0
+    for lo, hi in _slices(n, count, rows):
+        b = None if bias_dev is None else bias_dev[lo:hi].cpu().numpy().astype(np.float64)
+        ex = orc.exact_scores(V_dev[lo:hi].cpu().numpy(), q, metric, bias=b)
+        better = np.nonzero(ex > kth + slack)[0] + lo + row_base
+        missing = [int(r) for r in better if int(r) not in returned]
+        assert not missing, f"rows {missing[:5]} in [{lo},{hi}) beat the k-th score {kth} but were left out ({metric})"
+
+
 # ------------------------------------------------------------------------------------------------
 # 4. properties at full size (N=10M d=384 fp16, top-100): fused == exact on device, validity of
 #    every returned row against float64 scores of those rows, recency, batches
@@ -302,11 +326,8 @@ def test_full_size_fused_equals_exact(big_fp16, orc, metric):
         ex = orc.exact_scores(rows, Q[qi].cpu().numpy(), metric)
         assert np.all(np.abs(ex - sc_h[qi]) <= 1e-3 * np.maximum(1, np.abs(ex)))
         assert np.all(np.diff(sc_h[qi]) <= 0) and np.unique(idx_h[qi]).size == 100
-        sl = V[:1_000_000].cpu().numpy()
-        ex_sl = orc.exact_scores(sl, Q[qi].cpu().numpy(), metric)
-        kth = sc_h[qi][-1]
-        better = np.nonzero(ex_sl > kth + 2e-3 * max(1.0, abs(kth)))[0]
-        assert set(better.tolist()) <= set(idx_h[qi].tolist()), "a clearly better row was left out"
+        # omission check by an independent scorer on 10 windows from row 0 to the LAST row (byte offsets past 4 GiB)
+        _assert_nothing_left_out(orc, V, Q[qi].cpu().numpy(), metric, idx_h[qi], sc_h[qi], 1e-3)
 
 
 def test_full_size_hamming_exact_properties(big_fp16, orc):
@@ -328,12 +349,8 @@ def test_full_size_hamming_exact_properties(big_fp16, orc):
         for s in np.unique(sc_h[qi]):
             run = idx_h[qi][sc_h[qi] == s]
             assert np.all(np.diff(run) > 0)
-        # boundary: on the first 2M rows no row beats the k-th score unless returned, and ties at the
-        # boundary are the lowest-indexed ones
-        sl = V[:2_000_000].cpu().numpy()
-        ex_sl = orc.exact_scores(sl, Q[qi].cpu().numpy(), "hamming_distance")
-        kth = sc_h[qi][-1]
-        assert set(np.nonzero(ex_sl > kth)[0].tolist()) <= set(idx_h[qi].tolist())
+        # boundary: no row of 10 windows spread over the whole matrix beats the k-th score unless returned (bit-exact)
+        _assert_nothing_left_out(orc, V, Q[qi].cpu().numpy(), "hamming_distance", idx_h[qi], sc_h[qi], 0.0)
 
 
 def test_full_size_batch_equals_singles(big_fp16):
@@ -1033,3 +1050,148 @@ def test_growable_index_append_matches_full_rebuild(orc):
         assert ix.has_nan
     finally:
         ix.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# 9. BASELINE configs 4 and 5 at full size, and a GPU-vs-oracle fuzz that is not a self-comparison
+# ------------------------------------------------------------------------------------------------
+def test_config4_100m_rows_eight_shards_merge_equals_single_index(orc):
+    """Config 4 (N=100M d=384 fp16, 8 row shards, all-gather + merge) on ONE GPU (76.8 GB fits in 288 GB): the eight
+    12.5M-row shards are scanned with their row_base, their packed records are laid out as the all-gather would and
+    merged by hdb_merge_topk_packed; the result must equal the single 100M-row index bit for bit, every returned row
+    re-scores in float64, and windows up to the LAST row (global ids >= 87.5M, byte offsets up to 76.8 GB) hold no
+    better row.  Data = bench.make_shard (block-seeded standard normal), queries = bench.make_queries."""
+    import torch
+    import bench
+    from hyperdb._native import GpuIndex, METRIC_IDS, merge_topk_packed, packed_bytes
+    n, d, k, parts, nq = 100_000_000, 384, 100, 8, 4
+    dev = torch.device("cuda", 0)
+    V, lo, hi = bench.make_shard(n, d, torch.float16, 0, 1, dev)
+    assert (lo, hi) == (0, n)
+    Q = bench.make_queries(nq, d, torch.float16, dev).float()
+    whole = GpuIndex(V)
+    shards = []
+    try:
+        per = n // parts
+        shards = [GpuIndex(V[p * per:(p + 1) * per], row_base=p * per) for p in range(parts)]
+        for metric in ("cosine_similarity", "dot_product"):
+            mid = METRIC_IDS[metric]
+            gi, gs, gst = whole.topk_device(Q, k, mid)
+            assert whole.stat("path") == 1 and whole.stat("mfma") == 1 and int(gst.abs().sum().item()) == 0
+            nb = packed_bytes(nq, k)
+            rec = torch.zeros((parts, nb), dtype=torch.uint8, device=dev)
+            for p, sh in enumerate(shards):
+                sh.topk_packed(Q, k, mid, rec[p])
+            mi, ms, mst = merge_topk_packed(rec, parts, nq, k)
+            assert int(mst.abs().sum().item()) == 0
+            assert torch.equal(mi, gi) and torch.equal(ms, gs), metric
+            gi_h, gs_h = gi.cpu().numpy(), gs.cpu().numpy()
+            assert gi_h.max() < n and gi_h.min() >= 0
+            for qi in range(nq):
+                rows = V[gi[qi]].cpu().numpy()
+                ex = orc.exact_scores(rows, Q[qi].cpu().numpy(), metric)
+                assert np.all(np.abs(ex - gs_h[qi]) <= 1e-3 * np.maximum(1, np.abs(ex))), (metric, qi)
+                assert np.all(np.diff(gs_h[qi]) <= 0) and np.unique(gi_h[qi]).size == k
+            assert (gi_h >= n - per).any(), "no hit from the last shard in 4 x 100 results?"
+            for qi in (0, nq - 1):
+                _assert_nothing_left_out(orc, V, Q[qi].cpu().numpy(), metric, gi_h[qi], gs_h[qi], 1e-3, count=12)
+        # the last shard alone, VALU scan (an independent kernel) == its MFMA scan
+        last = shards[-1]
+        a_i, a_s, _ = last.topk_device(Q[:2], k, METRIC_IDS["dot_product"])
+        last.set_option("use_mfma", 0)
+        b_i, b_s, _ = last.topk_device(Q[:2], k, METRIC_IDS["dot_product"])
+        assert last.stat("mfma") == 0 and torch.equal(a_i, b_i) and torch.allclose(a_s, b_s, rtol=2e-6, atol=2e-5)
+        assert int(a_i.min().item()) >= n - per
+    finally:
+        for sh in shards + [whole]:
+            sh.close()
+        del V
+        torch.cuda.empty_cache()
+
+
+def test_config5_full_size_euclidean_with_time_decay(orc):
+    """Config 5 at full size: N=10M d=768 fp16, 64 queries, euclidean similarity + recency term (timestamps uniform
+    over 30 days, recency_bias 0.5).  MFMA pass vs float64 scores of the returned rows (all 64 queries), vs the VALU
+    scan (independent kernel) and vs the on-device exact selection; omission windows over the whole row range."""
+    import torch
+    import bench
+    from hyperdb._native import GpuIndex, METRIC_IDS
+    n, d, k, nq = 10_000_000, 768, 100, 64
+    dev = torch.device("cuda", 0)
+    V, _, _ = bench.make_shard(n, d, torch.float16, 0, 1, dev)
+    Q = bench.make_queries(nq, d, torch.float16, dev).float()
+    g = torch.Generator(device=dev).manual_seed(99)
+    ts = 1.7e9 + torch.rand(n, generator=g, device=dev, dtype=torch.float64) * 30 * 86400.0
+    ix = GpuIndex(V)
+    try:
+        mid = METRIC_IDS["euclidean_metric"]
+        for rb in (0.5, 0.02):      # 0.5: the newest rows dominate; 0.02: distance and recency are of the same size
+            ix.set_recency(ts, rb)
+            bias = (rb * torch.exp(ts - ts.max())).float()
+            mi, ms, st = ix.topk_device(Q, k, mid)
+            assert ix.stat("mfma") == 1 and ix.stat("path") == 1 and int(st.abs().sum().item()) == 0
+            mi_h, ms_h = mi.cpu().numpy(), ms.cpu().numpy()
+            for qi in range(nq):
+                rows = V[mi[qi]].cpu().numpy()
+                ex = orc.exact_scores(rows, Q[qi].cpu().numpy(), "euclidean_metric", bias=bias[mi[qi]].cpu().numpy().astype(np.float64))
+                assert np.all(np.abs(ex - ms_h[qi]) <= 1e-3), (rb, qi, float(np.abs(ex - ms_h[qi]).max()))
+                assert np.all(np.diff(ms_h[qi]) <= 0) and np.unique(mi_h[qi]).size == k
+            ei, es, _ = ix.topk_device(Q[:8], k, mid, exact=True)
+            sa, sb = torch.sort(ms[:8], dim=-1, descending=True)[0], torch.sort(es, dim=-1, descending=True)[0]
+            assert bool(((sa - sb).abs() <= 1e-6 * sa.abs().clamp(min=1e-3)).all()), "fused vs exact selection"
+            ix.set_option("use_mfma", 0)
+            vi, vs, _ = ix.topk_device(Q[:3], k, mid)
+            ix.set_option("use_mfma", 1)
+            vi_h, vs_h = vi.cpu().numpy(), vs.cpu().numpy()
+            for qi in range(3):
+                assert orc.same_result_modulo_ties(mi_h[qi], ms_h[qi], vi_h[qi], vs_h[qi], 2e-5), (rb, qi)
+            for qi in (0, nq - 1):
+                _assert_nothing_left_out(orc, V, Q[qi].cpu().numpy(), "euclidean_metric", mi_h[qi], ms_h[qi], 1e-3,
+                                         bias_dev=bias, count=8, rows=100_000)
+    finally:
+        ix.close()
+        del V
+        torch.cuda.empty_cache()
+
+
+def test_fuzz_gpu_against_oracle(orc):
+    """Seeded slice of tests/fuzz_oracle.py inside the suite: random shapes, GPU result vs the oracle's float64
+    comparator (not a self-comparison) -- seven metrics x three dtypes x {bias, no bias}, MFMA and odd dimensions,
+    single queries and batches, duplicate rows, a query equal to a stored row."""
+    from hyperdb._native import GpuIndex, METRIC_IDS
+    rng = np.random.default_rng(20261004)
+    combos = [(m, dt) for m in GPU_METRICS for dt in (np.float16, np.float32, np.float64)]
+    cases = combos + combos + [combos[i] for i in rng.permutation(len(combos))[:21]]          # 63 cases
+    seen = set()
+    for case, (metric, dt) in enumerate(cases):
+        d = int(rng.choice([128, 256, 384, 512, 768, 1024, 24, 100, 33, 200]))
+        n = int(rng.integers(8200, 40_000)) if rng.random() < 0.8 else int(rng.integers(2, 8192))
+        nq = int(rng.choice([1, 1, 2, 5, 9, 33]))
+        k = int(rng.choice([1, 5, 40, 100]))
+        with_bias = case >= len(combos) and case < 2 * len(combos)
+        V = rng.standard_normal((n, d)).astype(np.float32).astype(dt)
+        if rng.random() < 0.2:
+            V[rng.integers(0, n, size=20)] = V[0]
+        Q = rng.standard_normal((nq, d)).astype(np.float32).astype(dt)
+        if rng.random() < 0.3:
+            Q[0] = V[n // 2]
+        ix = GpuIndex(V)
+        try:
+            bias = None
+            if with_bias:
+                ts = 1.7e9 + rng.uniform(0, 86400.0, size=n)
+                ix.set_recency(ts, 0.4)
+                bias = 0.4 * np.exp(ts - ts.max())
+            idx, sc = ix.topk(Q, min(k, n), METRIC_IDS[metric])
+            tol = _tol(dt, metric)
+            if metric == "hamming_distance" and bias is not None:
+                tol = 1e-5
+            for qi in range(nq):
+                orc.check_topk(idx[qi], sc[qi], V, Q[qi].copy(), metric, k, bias=bias, tol=tol)
+            seen.add((metric, np.dtype(dt).name, with_bias, bool(ix.stat("mfma"))))
+        except AssertionError as e:
+            raise AssertionError(f"case {case}: n={n} d={d} {np.dtype(dt).name} nq={nq} k={k} {metric} bias={with_bias} "
+                                 f"mfma={ix.stat('mfma')} path={ix.stat('path')}: {e}") from e
+        finally:
+            ix.close()
+    assert len({(m, t) for m, t, _, _ in seen}) == 21 and any(b for _, _, b, _ in seen) and any(f for _, _, _, f in seen)

@@ -176,3 +176,12 @@ def test_comparator_accepts_reference_and_rejects_wrong(golden_dir):
                 bad[0] = worst          # replace the best hit by the worst row
                 with pytest.raises(AssertionError):
                     orc.check_topk(*orc.canonical(bad, exact[bad]), V, q, c["metric"], c["top_k"], tol=tol)
+
+
+def test_config1_plumbing_golden(golden_dir):
+    """BASELINE config 1 (151 documents, d=384, cosine top-5 via numpy on the CPU, no GPU): the oracle reproduces the
+    reference's answer on the committed fixture bit for bit (tests/golden/c1.npz, made by make_golden.py c1)."""
+    g = np.load(os.path.join(golden_dir, "c1.npz"))
+    idx, sc = orc.rank(g["V"].copy(), g["q"].copy(), top_k=5, metric="cosine_similarity")
+    assert np.array_equal(idx, g["ref_idx"]) and np.array_equal(sc, g["ref_scores"])
+    assert idx[0] == 142 and sc.dtype == np.float64

@@ -29,6 +29,15 @@ class OracleEngine:
         self.V, self.row_base, self.fail_query = V_local, row_base, fail_query
         self.device = torch.device("cpu")
         self.exact_calls = 0
+        self.bias = None
+        self.ts_max_seen = None
+
+    def local_ts_max(self, timestamps):
+        return float(np.max(np.asarray(timestamps, dtype=np.float64)))
+
+    def set_recency(self, timestamps, recency_bias, ts_max):
+        self.ts_max_seen = ts_max
+        self.bias = (recency_bias * np.exp(np.asarray(timestamps, dtype=np.float64) - ts_max)).astype(np.float32)
 
     def packed_bytes(self, nq, k):
         return self.nat.packed_bytes(nq, k)        # the C function: layout comes from the library
@@ -49,6 +58,8 @@ class OracleEngine:
             self.exact_calls += 1
         for qi in range(nq):
             ex = self.orc.exact_scores(self.V, Q[qi].numpy(), METRICS[metric_id]).astype(np.float32)
+            if self.bias is not None:
+                ex = ex + self.bias
             order = np.lexsort((np.arange(len(ex)), -ex))[:k]
             idx[qi, :len(order)] = order + self.row_base
             sc[qi, :len(order)] = ex[order]
@@ -79,7 +90,7 @@ class OracleEngine:
         return Q[torch.as_tensor(which)]
 
 
-def _worker(rank, world, port, n, d, k, metric_id, fail_rank, out_dir):
+def _worker(rank, world, port, n, d, k, metric_id, fail_rank, out_dir, recency=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "local-hyperdb_amd"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -94,8 +105,12 @@ def _worker(rank, world, port, n, d, k, metric_id, fail_rank, out_dir):
         lo, hi = shard_bounds(n, world, granule=16)[rank]
         eng = OracleEngine(V[lo:hi], lo, fail_query=2 if rank == fail_rank else None)
         sh = ShardedIndex(None, n_total=n, group=dist.group.WORLD, engine=eng)
+        if recency:      # rows get newer with the row id: every shard has a different local maximum
+            ts = 1.7e9 + np.arange(n, dtype=np.float64) * 0.002
+            sh.set_recency(ts[lo:hi], 5.0)
         idx, sc = sh.query(Q, k, metric_id)
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), idx=idx, sc=sc, exact_calls=eng.exact_calls, lo=lo, hi=hi)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), idx=idx, sc=sc, exact_calls=eng.exact_calls, lo=lo, hi=hi,
+                 ts_max=(eng.ts_max_seen if eng.ts_max_seen is not None else np.nan))
     finally:
         dist.destroy_process_group()
 
@@ -143,6 +158,32 @@ def test_eight_rank_gloo_matches_global(tmp_path):
         ex = orc.exact_scores(V, Q[qi], METRICS[metric_id]).astype(np.float32)
         want = np.lexsort((np.arange(n), -ex))[:k]
         assert np.array_equal(ranks[0]["idx"][qi], want) and np.array_equal(ranks[0]["sc"][qi], ex[want])
+
+
+def test_recency_uses_the_global_newest_timestamp(tmp_path):
+    """Shards whose timestamp maxima differ must normalise exp(ts - max) by the GLOBAL maximum (one all-reduce in
+    ShardedIndex.set_recency); with per-shard maxima the merged top-k would differ from the single-matrix answer
+    (reference ranking_algorithm.py:183)."""
+    from oracle import ranking_oracle as orc
+    world, n, d, k, metric_id = 2, 1000, 24, 10, 1
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, n, d, k, metric_id, None, str(tmp_path), True), nprocs=world, join=True)
+    rng = np.random.default_rng(77)
+    V = rng.standard_normal((n, d)).astype(np.float32)
+    V[n // 2 + 3] = V[5]
+    Q = rng.standard_normal((4, d)).astype(np.float32)
+    ts = 1.7e9 + np.arange(n, dtype=np.float64) * 0.002
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert float(r0["ts_max"]) == float(r1["ts_max"]) == ts.max()
+    assert np.array_equal(r0["idx"], r1["idx"])
+    for qi in range(4):
+        oi, osc = orc.rank(V, Q[qi], top_k=k, metric=METRICS[metric_id], timestamps=ts, recency_bias=5.0)
+        assert np.array_equal(r0["idx"][qi], oi), (qi, r0["idx"][qi], oi)
+        assert np.allclose(r0["sc"][qi], osc, atol=1e-5)
+    # with per-shard maxima rank 0's rows would get the bias of rank 1's newest rows: a different answer
+    wrong = np.concatenate([5.0 * np.exp(ts[:496] - ts[:496].max()), 5.0 * np.exp(ts[496:] - ts.max())])
+    ex = orc.exact_scores(V, Q[0], METRICS[metric_id]) + wrong
+    assert not np.array_equal(np.argsort(-ex, kind="stable")[:k], r0["idx"][0])
 
 
 def test_shard_bounds_cover_everything():
