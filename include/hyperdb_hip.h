@@ -87,6 +87,9 @@ int hdb_index_update(hdb_index* ix, const void* dev_V, int64_t n, void* stream);
 int hdb_index_rebase(hdb_index* ix, const void* dev_V);
 int hdb_index_extend(hdb_index* ix, int64_t new_n, void* stream);
 
+/* Global row id of local row 0 (see hdb_index_create): a shard's base moves when an earlier shard grows or is compacted. */
+int hdb_index_set_row_base(hdb_index* ix, int64_t row_base);
+
 /* Compaction after HyperDB.remove_document (hyperdb.py:691-766; the reference rebuilds self.vectors on the host with
  * np.vstack / a boolean mask, :721-728): the m kept rows dev_rows[0..m) (ascending local row ids, int64, device) are
  * gathered into dev_V_out (m x d, caller-owned, must not alias the current matrix) in one pass at HBM speed, and the
@@ -161,6 +164,22 @@ int hdb_merge_topk(const int64_t* dev_idx_parts, const float* dev_score_parts, i
 int64_t hdb_packed_bytes(int32_t nq, int32_t k);
 int hdb_merge_topk_packed(const void* dev_gathered, int32_t parts, int32_t nq, int32_t k, int64_t* dev_idx,
                           float* dev_score, int32_t* dev_status, int device, void* stream);
+
+/* Single-process multi-GPU group: HyperDB.query() (hyperdb.py:1584) is a single-process
+ * call, so the row-sharded matrix must be reachable without a launcher.  A group is `parts` row shards, each an hdb_index
+ * created on its own device with its row_base (a device may hold several shards).  hdb_group_topk_host uploads the
+ * queries (HOST memory, nq x d float32, or float64 for F64 matrices) to every shard's device, runs hdb_topk on every
+ * shard concurrently (one parked worker thread and one stream per shard), lets each shard's last kernel store its packed
+ * record into a pinned, portable host buffer that every device can write, merges the `parts` records on shard 0's
+ * device straight into pinned host memory and returns the merged packed record (hdb_packed_bytes layout) in
+ * host_record.  Queries whose sampled threshold failed on any shard are re-run through hdb_topk_exact on every shard
+ * before returning: on return every status word is 0 except HDB_Q_NAN.  Bias / mask are set per shard on the shards'
+ * own handles (recency: pass the GLOBAL newest timestamp as ts_max to hdb_recency_bias).  parts * k <= 8192.
+ * The group borrows the shard handles: destroy the group first, then the shards. */
+typedef struct hdb_group hdb_group;
+int hdb_group_create(hdb_group** out, hdb_index* const* shards, int32_t parts);
+int hdb_group_topk_host(hdb_group* g, const void* host_Q, int32_t nq, int32_t k, int metric, void* host_record);
+void hdb_group_destroy(hdb_group* g);
 
 /* Largest k served by the selection kernels.  hdb_topk / hdb_topk_exact accept any k: above HDB_MAX_K (on a
  * matrix of more than 8192 rows) they materialise the scores of each query and radix-sort them (cold path,

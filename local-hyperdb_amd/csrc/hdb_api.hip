@@ -200,6 +200,13 @@ extern "C" int hdb_index_rebase(hdb_index* ix, const void* dev_V) {
     return HDB_OK;
 }
 
+extern "C" int hdb_index_set_row_base(hdb_index* ix, int64_t row_base) {
+    if (!ix) return fail(HDB_ERR_ARG, "hdb_index_set_row_base: null index");
+    if (row_base < 0) return fail(HDB_ERR_ARG, "hdb_index_set_row_base: row_base must be >= 0");
+    ix->row_base = row_base;
+    return HDB_OK;
+}
+
 extern "C" int hdb_index_extend(hdb_index* ix, int64_t new_n, void* stream) {
     if (!ix) return fail(HDB_ERR_ARG, "hdb_index_extend: null index");
     if (new_n < ix->n) return fail(HDB_ERR_ARG, "hdb_index_extend: new_n must not shrink the matrix (use hdb_index_update)");
@@ -751,5 +758,207 @@ extern "C" int hdb_recency_bias(const double* dev_ts, int64_t n, double recency_
     if (n == 0) return HDB_OK;
     HIP_TRY(hipSetDevice(device));
     LAUNCH_TRY(hdb_launch_recency(dev_ts, n, recency_bias, ts_max, dev_out, stream));
+    return HDB_OK;
+}
+
+// ================================================================================================
+// Single-process multi-GPU group: one row shard per entry (its own hdb_index, device and stream), queried together
+// behind ONE call -- what HyperDB.query() (hyperdb/hyperdb.py:1584, a single-process call) needs to reach several
+// GPUs without torchrun.  Per call:
+//   worker thread p (one per shard, parked on a condition variable between calls; launching 8 shards' pipelines from one
+//   host thread would serialise ~8 x 20 us of launch work, more than a shard's 150 us scan):
+//       H2D copy of the queries -> hdb_topk on the shard's own stream, results stored by the last kernel STRAIGHT into
+//       slice p of a pinned, portable host buffer (every device can write it: the "peer-readable record buffer") -> event
+//   calling thread: merge stream (device of shard 0) waits for the P events, hdb_merge_kernel reads the P records and
+//       stores the merged record into pinned host memory, one hipStreamSynchronize.
+// The exchange unit is the same packed record as the multi-process path (hdb_packed_bytes); it is 1.2 KB per shard at
+// nq=1, k=100, so the step is latency-bound and needs no collective library in-process.  Queries whose sampled
+// threshold failed on any shard are re-run on every shard through the exact selection and merged again.
+// ================================================================================================
+#include <thread>
+#include <mutex>
+#include <condition_variable>
+
+struct hdb_group {
+    int parts = 0;
+    std::vector<hdb_index*> ix;
+    std::vector<hipStream_t> st;
+    std::vector<hipEvent_t> ev;
+    std::vector<void*> qdev;
+    std::vector<size_t> qcap;
+    int merge_dev = 0;
+    hipStream_t merge_st = nullptr;
+    char* gather = nullptr; size_t gather_bytes = 0;     // pinned + portable host memory: parts records
+    char* out = nullptr; size_t out_bytes = 0;           // pinned + portable host memory: the merged record
+    // workers
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    uint64_t job_seq = 0;
+    int pending = 0;
+    bool stop = false;
+    // current job (written under mu before job_seq moves)
+    const void* host_Q = nullptr; size_t q_bytes = 0;
+    int nq = 0, k = 0, metric = 0; bool exact = false; size_t stride = 0;
+    std::vector<int> rc;
+    std::vector<std::string> err;
+};
+
+static void group_worker(hdb_group* g, int p) {
+    (void)hipSetDevice(g->ix[p]->device);
+    uint64_t seen = 0;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(g->mu);
+            g->cv_job.wait(lk, [&] { return g->stop || g->job_seq != seen; });
+            if (g->stop) return;
+            seen = g->job_seq;
+        }
+        int rc = HDB_OK;
+        std::string msg;
+        hdb_index* ix = g->ix[p];
+        hipStream_t st = g->st[p];
+        hipError_t e = hipSuccess;
+        if (g->q_bytes > g->qcap[p]) {
+            if (g->qdev[p]) { (void)hipStreamSynchronize(st); (void)hipFree(g->qdev[p]); g->qdev[p] = nullptr; g->qcap[p] = 0; }
+            e = hipMalloc(&g->qdev[p], g->q_bytes * 2);
+            if (e == hipSuccess) g->qcap[p] = g->q_bytes * 2;
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(g->qdev[p], g->host_Q, g->q_bytes, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) { rc = HDB_ERR_HIP; msg = std::string("hdb_group: query upload: ") + hipGetErrorString(e); }
+        if (rc == HDB_OK) {
+            char* rec = g->gather + (size_t)p * g->stride;
+            int64_t* d_idx = reinterpret_cast<int64_t*>(rec);
+            float* d_sc = reinterpret_cast<float*>(rec + (size_t)g->nq * g->k * 8);
+            int32_t* d_st = reinterpret_cast<int32_t*>(rec + (size_t)g->nq * g->k * 12);
+            rc = g->exact ? hdb_topk_exact(ix, g->qdev[p], g->nq, g->k, g->metric, d_idx, d_sc, d_st, st)
+                          : hdb_topk(ix, g->qdev[p], g->nq, g->k, g->metric, d_idx, d_sc, d_st, st);
+            if (rc != HDB_OK) msg = hdb_last_error();
+        }
+        if (rc == HDB_OK) {
+            e = hipEventRecord(g->ev[p], st);
+            if (e != hipSuccess) { rc = HDB_ERR_HIP; msg = std::string("hdb_group: event: ") + hipGetErrorString(e); }
+        }
+        {
+            std::lock_guard<std::mutex> lk(g->mu);
+            g->rc[p] = rc; g->err[p] = msg;
+            if (--g->pending == 0) g->cv_done.notify_all();
+        }
+    }
+}
+
+extern "C" void hdb_group_destroy(hdb_group* g) {
+    if (!g) return;
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        g->stop = true;
+    }
+    g->cv_job.notify_all();
+    for (auto& t : g->th) if (t.joinable()) t.join();
+    for (int p = 0; p < (int)g->st.size(); ++p) {
+        (void)hipSetDevice(g->ix[p]->device);
+        if (g->st[p]) { (void)hipStreamSynchronize(g->st[p]); (void)hipStreamDestroy(g->st[p]); }
+        if (p < (int)g->ev.size() && g->ev[p]) (void)hipEventDestroy(g->ev[p]);
+        if (p < (int)g->qdev.size() && g->qdev[p]) (void)hipFree(g->qdev[p]);
+    }
+    (void)hipSetDevice(g->merge_dev);
+    if (g->merge_st) { (void)hipStreamSynchronize(g->merge_st); (void)hipStreamDestroy(g->merge_st); }
+    if (g->gather) (void)hipHostFree(g->gather);
+    if (g->out) (void)hipHostFree(g->out);
+    delete g;
+}
+
+extern "C" int hdb_group_create(hdb_group** out, hdb_index* const* shards, int32_t parts) {
+    if (!out || !shards) return fail(HDB_ERR_ARG, "hdb_group_create: null argument");
+    if (parts < 1 || parts > 64) return fail(HDB_ERR_ARG, "hdb_group_create: 1..64 shards");
+    for (int p = 0; p < parts; ++p) {
+        if (!shards[p]) return fail(HDB_ERR_ARG, "hdb_group_create: null shard");
+        if (shards[p]->d != shards[0]->d || shards[p]->dtype != shards[0]->dtype)
+            return fail(HDB_ERR_ARG, "hdb_group_create: shards must share d and dtype");
+    }
+    hdb_group* g = new hdb_group();
+    g->parts = parts;
+    g->ix.assign(shards, shards + parts);
+    g->st.assign(parts, nullptr); g->ev.assign(parts, nullptr); g->qdev.assign(parts, nullptr); g->qcap.assign(parts, 0);
+    g->rc.assign(parts, 0); g->err.assign(parts, std::string());
+    g->merge_dev = shards[0]->device;
+    hipError_t e = hipSuccess;
+    for (int p = 0; p < parts && e == hipSuccess; ++p) {
+        e = hipSetDevice(g->ix[p]->device);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->st[p], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev[p], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipSetDevice(g->merge_dev);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->merge_st, hipStreamNonBlocking);
+    if (e != hipSuccess) { hdb_group_destroy(g); return fail(HDB_ERR_HIP, std::string("hdb_group_create: ") + hipGetErrorString(e)); }
+    for (int p = 0; p < parts; ++p) g->th.emplace_back(group_worker, g, p);
+    *out = g;
+    return HDB_OK;
+}
+
+// one round over all shards: wake the workers, wait until every pipeline is ENQUEUED, then merge on the merge stream
+static int group_round(hdb_group* g, const void* host_Q, size_t q_bytes, int nq, int k, int metric, bool exact, char* merged) {
+    {
+        std::lock_guard<std::mutex> lk(g->mu);
+        g->host_Q = host_Q; g->q_bytes = q_bytes; g->nq = nq; g->k = k; g->metric = metric; g->exact = exact;
+        g->stride = (size_t)hdb_packed_bytes(nq, k);
+        g->pending = g->parts;
+        ++g->job_seq;
+    }
+    g->cv_job.notify_all();
+    {
+        std::unique_lock<std::mutex> lk(g->mu);
+        g->cv_done.wait(lk, [&] { return g->pending == 0; });
+    }
+    for (int p = 0; p < g->parts; ++p)
+        if (g->rc[p] != HDB_OK) {
+            for (int r = 0; r < g->parts; ++r) { (void)hipSetDevice(g->ix[r]->device); (void)hipStreamSynchronize(g->st[r]); }
+            return fail(g->rc[p], "shard " + std::to_string(p) + ": " + g->err[p]);
+        }
+    HIP_TRY(hipSetDevice(g->merge_dev));
+    for (int p = 0; p < g->parts; ++p) HIP_TRY(hipStreamWaitEvent(g->merge_st, g->ev[p], 0));
+    const int64_t stride = (int64_t)g->stride;
+    LAUNCH_TRY(hdb_launch_merge(g->gather, stride, g->gather + (int64_t)nq * k * 8, stride, g->gather + (int64_t)nq * k * 12, stride,
+                                g->parts, nq, (uint32_t)k, reinterpret_cast<int64_t*>(merged),
+                                reinterpret_cast<float*>(merged + (size_t)nq * k * 8),
+                                reinterpret_cast<int32_t*>(merged + (size_t)nq * k * 12), g->merge_st));
+    HIP_TRY(hipStreamSynchronize(g->merge_st));
+    return HDB_OK;
+}
+
+static int group_pinned(char** buf, size_t* have, size_t need) {
+    if (need <= *have) return HDB_OK;
+    if (*buf) { HIP_TRY(hipHostFree(*buf)); *buf = nullptr; *have = 0; }
+    need = align_up(need * 2, 4096);
+    HIP_TRY(hipHostMalloc((void**)buf, need, hipHostMallocPortable | hipHostMallocMapped));
+    *have = need;
+    return HDB_OK;
+}
+
+extern "C" int hdb_group_topk_host(hdb_group* g, const void* host_Q, int32_t nq, int32_t k, int metric, void* host_record) {
+    if (!g || !host_Q || !host_record) return fail(HDB_ERR_ARG, "hdb_group_topk_host: null argument");
+    if (nq <= 0 || k <= 0) return fail(HDB_ERR_ARG, "hdb_group_topk_host: nq and k must be positive");
+    if ((int64_t)g->parts * k > HDB_CAND_CAP) return fail(HDB_ERR_UNSUPPORTED, "hdb_group_topk_host: parts*k exceeds 8192");
+    const size_t bytes = (size_t)hdb_packed_bytes(nq, k);
+    const size_t qelem = g->ix[0]->dtype == HDB_F64 ? 8 : 4;
+    const size_t q_row = (size_t)g->ix[0]->d * qelem;
+    HIP_TRY(hipSetDevice(g->merge_dev));
+    for (int p = 0; p < g->parts; ++p) { HIP_TRY(hipSetDevice(g->ix[p]->device)); HIP_TRY(hipStreamSynchronize(g->st[p])); }   // buffers may be re-sized
+    HIP_TRY(hipSetDevice(g->merge_dev));
+    int rc = group_pinned(&g->gather, &g->gather_bytes, bytes * g->parts); if (rc) return rc;
+    rc = group_pinned(&g->out, &g->out_bytes, bytes); if (rc) return rc;
+    rc = group_round(g, host_Q, q_row * nq, nq, k, metric, false, g->out); if (rc) return rc;
+    memcpy(host_record, g->out, bytes);
+    int32_t* h_st = reinterpret_cast<int32_t*>(static_cast<char*>(host_record) + (size_t)nq * k * 12);
+    std::vector<int> bad;
+    for (int q = 0; q < nq; ++q) if (h_st[q] & (HDB_Q_UNDERFLOW | HDB_Q_OVERFLOW)) bad.push_back(q);
+    // rare: a shard's sampled threshold failed -> that query goes through the exact selection on EVERY shard, merged again
+    for (int q : bad) {
+        rc = group_round(g, static_cast<const char*>(host_Q) + (size_t)q * q_row, q_row, 1, k, metric, true, g->out); if (rc) return rc;
+        char* hr = static_cast<char*>(host_record);
+        memcpy(hr + (size_t)q * k * 8, g->out, (size_t)k * 8);
+        memcpy(hr + (size_t)nq * k * 8 + (size_t)q * k * 4, g->out + (size_t)k * 8, (size_t)k * 4);
+        h_st[q] = *reinterpret_cast<int32_t*>(g->out + (size_t)k * 12);
+    }
     return HDB_OK;
 }

@@ -27,6 +27,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 static __device__ unsigned long long hdb_clock_buf[4 * HDB_CLOCK_WGS];
 #endif
 
+// Experiment switches for the 256-query ("heavy") pass, A/B-timed by tools/exp_q256.py (bit mask):
+//   1  the staging of tile i+2 is spread over the MFMA phase (A waves: one 1-KiB piece behind each of the first NG
+//      k-steps, B waves: behind the last NG) instead of issued as one block of NG pieces
+//   2  B waves issue the first fragment reads of tile i BEFORE their deferred epilogue of tile i-1
+//   4  s_setprio 1 for waves 4-7 (the arbitration losers of each SIMD), once, before the tile loop
+//   8  s_setprio 1 for waves 0-3 instead
+#ifndef HDB_MFMA_EXP
+#define HDB_MFMA_EXP 0
+#endif
+
 #define HDB_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define HDB_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
@@ -174,31 +184,37 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
     // Stage tile number t (global tile index) into ring slot st: NG LDS-DMA pieces of 1 KiB per wave,
     // non-temporal (V is read once per pass by exactly one CU: +2-3 % on the HBM-bound shapes), plus the
     // per-row aux values (B waves only).  Only the last tile of the matrix can be ragged.
-    auto issue = [&](int64_t t, int st) {
+    // piece j (0..NG-1) of tile t -> ring slot st
+    auto issue_piece = [&](int64_t t, int st, int j) {
         if ((HDB_MFMA_KNOCKOUT & 2) && t >= (int64_t)blockIdx.x + 3 * gstep) return;
         const int64_t row0 = hdb_tile_index(t, tstride) * R;
         const int64_t last = n_rows - 1 - row0;          // >= 0
         char* sdst = smem + st * STAGE;
         const char* tile_base = Vb + row0 * (int64_t)ROWB;             // wave-uniform
         if (last >= R - 1) {
-#pragma unroll
-            for (int j = 0; j < NG; ++j)
-                __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(tile_base + (unsigned int)g_off[j]),
-                                                 HDB_LDS_PTR(sdst + (w + 8 * j) * 1024), 16, 0, 2);
+            __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(tile_base + (unsigned int)g_off[j]),
+                                             HDB_LDS_PTR(sdst + (w + 8 * j) * 1024), 16, 0, 2);
         } else {                                                        // clamp rows past the end to the last row
-#pragma unroll
-            for (int j = 0; j < NG; ++j) {
-                const int r = g_off[j] / ROWB;
-                const int rr = r <= (int)last ? r : (int)last;
-                const unsigned int off = (unsigned int)(g_off[j] + (rr - r) * ROWB);
-                __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(tile_base + off), HDB_LDS_PTR(sdst + (w + 8 * j) * 1024), 16, 0, 2);
-            }
+            const int r = g_off[j] / ROWB;
+            const int rr = r <= (int)last ? r : (int)last;
+            const unsigned int off = (unsigned int)(g_off[j] + (rr - r) * ROWB);
+            __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(tile_base + off), HDB_LDS_PTR(sdst + (w + 8 * j) * 1024), 16, 0, 2);
         }
+    };
+    auto issue_aux = [&](int64_t t, int st) {
+        if ((HDB_MFMA_KNOCKOUT & 2) && t >= (int64_t)blockIdx.x + 3 * gstep) return;
         if ((AUX0 || HAS_BIAS) && grpB) {
+            const int64_t row0 = hdb_tile_index(t, tstride) * R;
+            const int64_t last = n_rows - 1 - row0;
             const int64_t rr = lane <= last ? lane : last;
             if (AUX0) __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(aux0g + row0 + rr), HDB_LDS_PTR(auxbuf + (st * 2 + 0) * 64), 4, 0, 0);
             if (HAS_BIAS) __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(a.bias + row0 + rr), HDB_LDS_PTR(auxbuf + (st * 2 + 1) * 64), 4, 0, 0);
         }
+    };
+    auto issue = [&](int64_t t, int st) {
+#pragma unroll
+        for (int j = 0; j < NG; ++j) issue_piece(t, st, j);
+        issue_aux(t, st);
     };
 
     auto flush = [&]() {
@@ -295,6 +311,8 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
         for (int qt = 0; qt < QT; ++qt) filter1(tv[qt], row0, thr_cmp[qt], qinv_l[qt], ql[qt]);
     };
 
+    if ((HDB_MFMA_EXP & 4) && grpB) __builtin_amdgcn_s_setprio(1);
+    if ((HDB_MFMA_EXP & 8) && !grpB) __builtin_amdgcn_s_setprio(1);
     const int chk_shift = ntiles >= 65536 ? 4 : 0;
     const int64_t chk_mask = (1 << chk_shift) - 1;
 #if HDB_MFMA_CLOCK
@@ -322,19 +340,15 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
         // 5.4-5.7 TB/s on the HBM-bound shapes vs 4.7-5.0 with the pieces spread between the MFMAs).
         const bool more = i + 2 < my_tiles;
         const int st_next2 = st_cur == 0 ? 2 : st_cur - 1;
-        if (more && !(heavy && grpB)) issue(t_cur + 2 * gstep, st_next2);
+        constexpr bool SPREAD = (HDB_MFMA_EXP & 1) != 0 && KS >= 2 * NG;
+        const bool spread = SPREAD && heavy && wave_active;       // pieces ride behind the MFMAs of the k-steps
+        if (more && spread) issue_aux(t_cur + 2 * gstep, st_next2);
+        if (more && !spread && !(heavy && grpB)) issue(t_cur + 2 * gstep, st_next2);
         if (chk && ctl[chk_slot]) flush();
 
         if (wave_active) {
             const int64_t row0 = hdb_tile_index(t_cur, tstride) * R;
-            if (MODE == 1 && grpB && i > 0) filter(acc, row0_prev);        // deferred epilogue of tile i-1
-#pragma unroll
-            for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                    for (int e = 0; e < 4 * NGRP; ++e) acc[qt][rt][e] = 0.f;
-
+            if (!(HDB_MFMA_EXP & 2) && MODE == 1 && grpB && i > 0) filter(acc, row0_prev);        // deferred epilogue of tile i-1
             // A fragments: LDS reads issued two k-steps ahead of the MFMAs that consume them.  The reads
             // and their counted waits are inline asm so that hipcc cannot sink a read next to its use
             // (it otherwise emits read, lgkmcnt(0), MFMA per step and exposes the LDS latency every step).
@@ -367,6 +381,14 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
             };
 #pragma unroll
             for (int s = 0; s < PF && s < KS; ++s) fetch(s, abuf[s % (PF + 1)]);
+            // EXP 2: the fragment reads of tile i are in flight while B finishes tile i-1 in the VALU
+            if ((HDB_MFMA_EXP & 2) && MODE == 1 && grpB && i > 0) filter(acc, row0_prev);
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int e = 0; e < 4 * NGRP; ++e) acc[qt][rt][e] = 0.f;
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 if (s + PF < KS) fetch(s + PF, abuf[(s + PF) % (PF + 1)]);
@@ -376,6 +398,12 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
                 for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) acc[qt][rt] = Shape::mma(abuf[s % (PF + 1)][rt], Bq[qt][s], acc[qt][rt]);
+                if constexpr (SPREAD) {
+                    if (more && spread) {
+                        if (!grpB && s < NG) issue_piece(t_cur + 2 * gstep, st_next2, s);
+                        if (grpB && s >= KS - NG) issue_piece(t_cur + 2 * gstep, st_next2, s - (KS - NG));
+                    }
+                }
             }
 
             // ---- epilogue, first half: turn the dot products into the values that are stored (MODE 0) or
@@ -444,7 +472,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
                 else row0_prev = row0;
             }
         }
-        if (more && heavy && grpB) issue(t_cur + 2 * gstep, st_next2);      // B's half of the staging, after its MFMA phase
+        if (more && heavy && grpB && !spread) issue(t_cur + 2 * gstep, st_next2);      // B's half of the staging, after its MFMA phase
         st_cur = st_cur == 2 ? 0 : st_cur + 1;
     }
 #if HDB_MFMA_CLOCK

@@ -34,7 +34,8 @@ NAN_MESSAGE = "Vectors and query_vector should not contain NaN values."   # refe
 
 EXPORTS = (
     "hdb_version", "hdb_last_error", "hdb_index_create", "hdb_index_update", "hdb_index_rebase", "hdb_index_extend",
-    "hdb_index_gather", "hdb_index_destroy",
+    "hdb_index_gather", "hdb_index_set_row_base", "hdb_index_destroy",
+    "hdb_group_create", "hdb_group_topk_host", "hdb_group_destroy",
     "hdb_index_has_nan", "hdb_index_set_bias", "hdb_index_set_row_mask", "hdb_scores", "hdb_topk",
     "hdb_topk_exact", "hdb_merge_topk", "hdb_set_option", "hdb_get_stat", "hdb_recency_bias",
     "hdb_packed_bytes", "hdb_merge_topk_packed", "hdb_topk_host",
@@ -60,6 +61,11 @@ def _load():
     lib.hdb_index_rebase.argtypes = [vp, vp]
     lib.hdb_index_extend.argtypes = [vp, i64, vp]
     lib.hdb_index_gather.argtypes = [vp, vp, i64, vp, vp]
+    lib.hdb_index_set_row_base.argtypes = [vp, i64]
+    lib.hdb_group_create.argtypes = [ctypes.POINTER(vp), ctypes.POINTER(vp), i32]
+    lib.hdb_group_topk_host.argtypes = [vp, vp, i32, i32, ctypes.c_int, vp]
+    lib.hdb_group_destroy.argtypes = [vp]
+    lib.hdb_group_destroy.restype = None
     lib.hdb_index_destroy.argtypes = [vp]
     lib.hdb_index_destroy.restype = None
     lib.hdb_index_has_nan.argtypes = [vp, ctypes.POINTER(ctypes.c_int)]
@@ -77,7 +83,7 @@ def _load():
     lib.hdb_merge_topk_packed.argtypes = [vp, i32, i32, i32, vp, vp, vp, ctypes.c_int, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("hdb_last_error", "hdb_index_destroy", "hdb_packed_bytes"):
+        if name not in ("hdb_last_error", "hdb_index_destroy", "hdb_group_destroy", "hdb_packed_bytes"):
             fn.restype = ctypes.c_int
     lib.hdb_packed_bytes.restype = i64
     return lib
@@ -223,6 +229,14 @@ class GpuIndex:
         self._buf = None                                    # the old capacity buffer is released with the old matrix
         _check(_lib.hdb_index_update(self._h, ctypes.c_void_p(t.data_ptr()), self.n, _stream_ptr(self.device)),
                "hdb_index_update")
+
+    def set_row_base(self, row_base):
+        self.row_base = int(row_base)
+        _check(_lib.hdb_index_set_row_base(self._h, self.row_base), "hdb_index_set_row_base")
+
+    def host_matrix(self):
+        """The stored rows as a host array (one D2H copy; the resident copy stays the only one kept)."""
+        return self.V.cpu().numpy()
 
     def compact(self, keep_rows):
         """Keep only the rows `keep_rows` (ascending local row ids): device-side gather into a fresh allocation, the

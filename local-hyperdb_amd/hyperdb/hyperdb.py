@@ -23,7 +23,9 @@ Differences from the reference, all deliberate:
   * ``filters``: ``skip_doc`` and ``metadata`` equality become a device row mask, and so does the additive
     ``("mask", bool_array)`` filter; ``key`` (re-embeds sub-documents, hyperdb.py:1087) and ``sentence`` (text search,
     hyperdb.py:1136-1176) belong to the text pipeline and raise NotImplementedError;
-  * strings can be queried only when an ``embedding_function`` is supplied (no model download).
+  * strings can be queried only when an ``embedding_function`` is supplied (no model download);
+  * additive ``devices=[...]``: the matrix is row-sharded over several GPUs and every query runs on all of them in one
+    call of the same single-process API (``GpuGroup`` -> hdb_group_topk_host).
 Kept from the reference: argument names and defaults, metric whitelist and messages, the top_k warning,
 ``(document, score, source_index)`` / ``document`` return shapes, the LRU result cache, and the DOUBLE
 application of the recency decay when going through ``query()`` (hyperdb.py:1344 then
@@ -43,6 +45,7 @@ import numpy as np
 
 from . import ranking_algorithm as ranking
 from ._native import GpuIndex, METRIC_IDS
+from .group import GpuGroup
 
 __all__ = ["HyperDB"]
 
@@ -52,7 +55,8 @@ _METRICS = ['dot_product', 'cosine_similarity', 'euclidean_metric', 'manhattan_d
 
 class HyperDB:
     def __init__(self, documents=None, vectors=None, select_keys=None, embedding_function=None, fp_precision="float32",
-                 add_timestamp=False, metadata_keys=None, ann_metric="cosine", n_trees=10, cache_size=256, device=None):
+                 add_timestamp=False, metadata_keys=None, ann_metric="cosine", n_trees=10, cache_size=256, device=None,
+                 devices=None):
         if fp_precision not in ["float16", "float32", "float64"]:
             raise ValueError("Unsupported floating-point precision.")                       # hyperdb.py:65-66
         accepted = ["angular", "euclidean", "manhattan", "hamming", "dot", "cosine"]
@@ -67,6 +71,7 @@ class HyperDB:
             self.metadata_keys.append("timestamp")
         self.ann_metric, self.n_trees = ann_metric, n_trees          # accepted for compatibility; no ANN is built
         self.device = device
+        self.devices = list(devices) if devices else None      # several GPUs: the matrix is row-sharded over them (GpuGroup)
         self.documents, self.source_indices = [], []
         self._index = None
         self._dead = np.zeros(0, dtype=np.int64)     # tombstoned device rows (ascending); see remove_document
@@ -115,7 +120,7 @@ class HyperDB:
         self._ts_cache.clear()
         self.clear_cache()
         if self._index is None:
-            self._index = GpuIndex(vectors, device=self.device)
+            self._index = GpuGroup(vectors, self.devices) if self.devices else GpuIndex(vectors, device=self.device)
         else:
             self._index.append(vectors)
 
@@ -209,7 +214,7 @@ class HyperDB:
         here the only resident copy is the device one)."""
         if self._index is None:
             return None
-        host = self._index.V.cpu().numpy()
+        host = self._index.host_matrix()
         return host if self._dead.size == 0 else host[self._live_rows()]
 
     def size(self, with_chunks=False, metadata=None):
@@ -234,11 +239,15 @@ class HyperDB:
             query_input = tuple(query_input.ravel().tolist()) + (query_input.shape,)
         elif isinstance(query_input, list):
             query_input = tuple(np.asarray(query_input).ravel().tolist())
-        if filters is None:
-            hf = None
-        else:
-            hf = tuple((name, tuple(sorted(p.items())) if isinstance(p, dict) else tuple(p) if isinstance(p, list) else p)
-                       for name, p in filters)
+        def freeze(p):
+            if isinstance(p, dict):
+                return tuple(sorted(p.items()))
+            if isinstance(p, np.ndarray):                       # the additive ("mask", bool_array) filter
+                return (p.shape, p.dtype.str, p.tobytes())
+            if isinstance(p, (list, tuple)):
+                return tuple(p)
+            return p
+        hf = None if filters is None else tuple((name, freeze(p)) for name, p in filters)
         return (query_input, top_k, return_similarities, hf, recency_bias, timestamp_key, metric, ann_percent)
 
     # ---------------------------------------------------------------- helpers around the ranking call

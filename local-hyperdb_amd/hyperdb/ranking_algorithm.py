@@ -26,6 +26,7 @@ import torch
 
 from . import _native
 from ._native import GpuIndex, METRIC_IDS, NAN_MESSAGE
+from .group import GpuGroup
 
 __all__ = [
     "get_norm_vector", "dot_product", "cosine_similarity", "euclidean_metric", "manhattan_distance",
@@ -40,8 +41,8 @@ _ALL_METRICS = tuple(METRIC_IDS)
 class ResidentVectors:
     """Handle for a matrix registered on the GPU; pass it wherever ``vectors`` is expected."""
 
-    def __init__(self, vectors, device=None):
-        self.index = GpuIndex(vectors, device=device)
+    def __init__(self, vectors, device=None, devices=None):
+        self.index = GpuGroup(vectors, devices) if devices else GpuIndex(vectors, device=device)
         arr_dtype = vectors.dtype if hasattr(vectors, "dtype") else None
         self.np_dtype = _np_dtype_of(arr_dtype, self.index)
 
@@ -56,9 +57,10 @@ class ResidentVectors:
         self.index.close()
 
 
-def register_vectors(vectors, device=None):
-    """Upload ``vectors`` once; returns a handle usable in place of ``vectors``."""
-    return ResidentVectors(vectors, device=device)
+def register_vectors(vectors, device=None, devices=None):
+    """Upload ``vectors`` once; returns a handle usable in place of ``vectors``.  ``devices=[...]`` row-shards the matrix
+    over several GPUs behind the same handle (single process, see hyperdb/group.py)."""
+    return ResidentVectors(vectors, device=device, devices=devices)
 
 
 _TORCH2NP = {torch.float16: np.float16, torch.float32: np.float32, torch.float64: np.float64}
@@ -70,7 +72,7 @@ def _np_dtype_of(dt, index):
     if dt is not None:
         d = np.dtype(dt)
         return d
-    return np.dtype(_TORCH2NP[index.V.dtype])
+    return np.dtype(_TORCH2NP[(index.shards[0] if isinstance(index, GpuGroup) else index).V.dtype])
 
 
 def _resolve(vectors):
@@ -79,6 +81,8 @@ def _resolve(vectors):
         return vectors.index, vectors.np_dtype, False
     if isinstance(vectors, GpuIndex):
         return vectors, np.dtype(_TORCH2NP[vectors.V.dtype]), False
+    if isinstance(vectors, GpuGroup):
+        return vectors, np.dtype(_TORCH2NP[vectors.shards[0].V.dtype]), False
     if isinstance(vectors, torch.Tensor):
         ix = GpuIndex(vectors)
         return ix, np.dtype(_TORCH2NP.get(vectors.dtype, np.float64)), True

@@ -354,3 +354,68 @@ def test_save_load_round_trip_and_mask_filter(tmp_path, fmt, name):
     half = HyperDB(fp_precision="float16")
     half.load(path, format=fmt)                                    # lands in HBM in the requested precision
     assert half.vectors.dtype == np.float16 and half.query(q.astype(np.float16), top_k=1)[0][0]["name"] == "doc40"
+
+
+@pytest.mark.gpu
+def test_single_process_group_two_logical_shards_on_one_gpu():
+    """hdb_group_* behind the drop-in API: HyperDB(devices=[0, 0]) and
+    register_vectors(..., devices=[0, 0]) split the matrix into two row shards (both on cuda:0 here; one per GPU on a
+    node), run them concurrently and merge their packed records -- the answers must equal the unsharded index bit for
+    bit, including filters, recency with the GLOBAL newest timestamp, appends, removals and a forced exact re-run."""
+    import hyperdb.ranking_algorithm as ranking
+    from hyperdb import HyperDB
+    from hyperdb._native import METRIC_IDS
+    from oracle import ranking_oracle as orc
+    rng = np.random.default_rng(8)
+    n, d = 50_000, 384
+    V = rng.standard_normal((n, d)).astype(np.float32).astype(np.float16)
+    Q = rng.standard_normal((5, d)).astype(np.float16)
+    one = ranking.register_vectors(V)
+    two = ranking.register_vectors(V, devices=[0, 0])
+    try:
+        assert [s.n for s in two.index.shards] == [25_000, 25_000] and two.index.shards[1].row_base == 25_000
+        ts = 1.7e9 + np.arange(n) * 0.5                          # newest rows in the LAST shard: per-shard maxima differ
+        for metric in ("cosine_similarity", "dot_product", "euclidean_metric", "hamming_distance"):
+            for kw in ({}, {"timestamps": ts, "recency_bias": 0.3}):
+                a = ranking.rank_batch(one, Q.copy(), top_k=100, metric=metric, **kw)
+                b = ranking.rank_batch(two, Q.copy(), top_k=100, metric=metric, **kw)
+                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (metric, kw.keys())
+        i1, s1 = ranking.hyperDB_ranking_algorithm_sort(two, Q[0].copy(), top_k=10, metric="cosine_similarity")
+        oi, osc = orc.rank(V, Q[0].copy(), top_k=10, metric="cosine_similarity")
+        assert orc.same_result_modulo_ties(i1, s1, oi, osc, 1e-3)
+        assert np.allclose(ranking.dot_product(two, Q[1]), ranking.dot_product(one, Q[1]))
+        # a failed threshold on the shards (sample_target far too small) comes back through the exact selection
+        two.index.set_option("sample_target", 16)
+        bi, bs = two.index.topk(Q.astype(np.float32), 100, METRIC_IDS["dot_product"])
+        two.index.set_option("sample_target", 0)
+        ai, as_ = one.index.topk(Q.astype(np.float32), 100, METRIC_IDS["dot_product"])
+        assert np.array_equal(ai, bi) and np.array_equal(as_, bs)
+    finally:
+        one.close()
+        two.close()
+    # the facade on two shards: filters, double recency, append (goes behind the last shard), removal + compaction
+    docs = _docs(2000)
+    W = rng.standard_normal((2000, 64)).astype(np.float32)
+    ref = HyperDB(documents=[dict(x) for x in docs], vectors=W, metadata_keys=["timestamp", "info.type"], ann_metric="dot")
+    grp = HyperDB(documents=[dict(x) for x in docs], vectors=W, metadata_keys=["timestamp", "info.type"], ann_metric="dot", devices=[0, 0])
+    q = rng.standard_normal(64).astype(np.float32)
+
+    def same(**kw):
+        ra, rb_ = ref.query(q, **kw), grp.query(q, **kw)
+        assert [r[2] for r in ra] == [r[2] for r in rb_] and np.allclose([r[1] for r in ra], [r[1] for r in rb_], atol=1e-6), kw
+        assert [r[0]["name"] for r in ra] == [r[0]["name"] for r in rb_]
+    same(top_k=9)
+    same(top_k=9, metric="euclidean_metric", filters=[("skip_doc", 700), ("metadata", {"info.type": "odd"})])
+    same(top_k=9, metric="dot_product", recency_bias=0.7, timestamp_key="timestamp", filters=[("skip_doc", -300)])
+    extra = rng.standard_normal((300, 64)).astype(np.float32)
+    more_docs = [{"name": f"new{i}", "info": {"type": "odd"}, "timestamp": 1.8e9 + i} for i in range(300)]
+    ref.add([dict(x) for x in more_docs], vectors=extra)
+    grp.add([dict(x) for x in more_docs], vectors=extra)
+    same(top_k=12, metric="cosine_similarity")
+    gone = rng.choice(2300, size=900, replace=False).tolist()
+    ref.remove_document(gone)
+    grp.remove_document(gone)
+    assert grp._dead.size == 0 and grp._index.n == 1400 and [s.row_base for s in grp._index.shards][0] == 0
+    same(top_k=12, metric="cosine_similarity")
+    same(top_k=5, metric="manhattan_distance", filters=[("metadata", {"info.type": "even"})])
+    assert np.array_equal(ref.vectors, grp.vectors)
