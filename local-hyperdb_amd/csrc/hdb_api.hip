@@ -46,6 +46,9 @@ int hdb_mfma_supported(int dtype, int d, int metric);
 int hdb_mfma_tile_rows(int dtype, int d);
 int hdb_launch_mfma_scan(const ScanArgs* args, int dtype, int mode, int nq_launch, const void* q16, const float* sqnorm,
                          const float* qsq, const float* qscl, int max_blocks, int variant, void* stream);
+int hdb_mfma_fused_supported(int dtype, int d, int metric, int nq, uint32_t kk);
+size_t hdb_mfma_fused_ctl_bytes(void);
+int hdb_launch_mfma_fused(const ScanArgs* args, const FusedArgs* fa, int max_blocks, void* stream);
 int hdb_launch_q_to_f16(const float* Q, int nq, int d, void* q16, float* qscl, void* stream);
 int hdb_sort_temp_bytes(int64_t n, size_t* bytes);
 int hdb_launch_full_sort(const float* scores, int64_t n, int64_t k, int64_t row_base, uint32_t* work, void* temp, size_t temp_bytes,
@@ -98,6 +101,9 @@ struct hdb_index {
     // mask folded into a bias vector for the MFMA scan (owned, rebuilt per call: the mask and bias are borrowed)
     float* mbias = nullptr;
     int64_t mbias_rows = 0;
+    // control block of the single-launch pipeline (owned): counters + exchange granules, zero between calls
+    char* fctl = nullptr;
+    uint32_t fused_epoch = 0;
     // device copy of the result record of hdb_topk_host (owned)
     char* rec = nullptr;
     size_t rec_bytes = 0;
@@ -113,10 +119,12 @@ struct hdb_index {
     int64_t exact_bytes = (int64_t)1 << 30;
     int64_t bits_fused = 1;           // hamming / jaccard: try the sampled-threshold path first (exact path when it fails)
     int64_t host_direct = 1;          // hdb_topk_host: kernels write a pinned host record themselves (no D2H copy)
+    int64_t use_fused = 1;            // 1-4 dot / cosine queries on an fp16 matrix: the whole call in ONE kernel (hdb_mfma_fused.h)
+    int64_t fused_timeout_us = 2000;  // bound of every in-kernel spin of that kernel
     int64_t finalize_threads = 1024;  // workgroup size of hdb_finalize_kernel (256 | 512 | 1024)
     int64_t mfma_variant = 16;        // MFMA shape of the d=384 256-query pass (16 | 32)
     // stats of the last hdb_topk call
-    int64_t st_sample_rows = 0, st_sample_m = 0, st_path = 0, st_chunks = 0, st_mfma = 0, st_host_direct = 0;
+    int64_t st_sample_rows = 0, st_sample_m = 0, st_path = 0, st_chunks = 0, st_mfma = 0, st_host_direct = 0, st_fused = 0;
     // optional HIP-event timing of the dominant kernel (the pass over all of V)
     int64_t profile = 0;
     std::vector<hipEvent_t> ev_pool;      // pairs: [2i] start, [2i+1] stop
@@ -276,6 +284,7 @@ extern "C" void hdb_index_destroy(hdb_index* ix) {
     if (ix->bits) (void)hipFree(ix->bits);
     if (ix->pscale) (void)hipFree(ix->pscale);
     if (ix->mbias) (void)hipFree(ix->mbias);
+    if (ix->fctl) (void)hipFree(ix->fctl);
     if (ix->ws) (void)hipFree(ix->ws);
     if (ix->rec) (void)hipFree(ix->rec);
     for (hipEvent_t e : ix->ev_pool) (void)hipEventDestroy(e);
@@ -315,6 +324,8 @@ extern "C" int hdb_set_option(hdb_index* ix, const char* name, int64_t value) {
     else if (!strcmp(name, "finalize_threads")) { if (value == 256 || value == 512 || value == 1024) ix->finalize_threads = value; }
     else if (!strcmp(name, "mfma_variant")) { if (value == 16 || value == 32) ix->mfma_variant = value; }
     else if (!strcmp(name, "host_direct")) ix->host_direct = value;
+    else if (!strcmp(name, "use_fused")) ix->use_fused = value;
+    else if (!strcmp(name, "fused_timeout_us")) ix->fused_timeout_us = std::max<int64_t>(1, value);
     else if (!strcmp(name, "bits_fused")) ix->bits_fused = value;
     else if (!strcmp(name, "profile")) { ix->profile = value; ix->ev_used = 0; }
     else return fail(HDB_ERR_ARG, std::string("hdb_set_option: unknown option ") + name);
@@ -329,6 +340,7 @@ extern "C" int hdb_get_stat(hdb_index* ix, const char* name, int64_t* value) {
     else if (!strcmp(name, "chunks")) *value = ix->st_chunks;
     else if (!strcmp(name, "mfma")) *value = ix->st_mfma;
     else if (!strcmp(name, "host_direct")) *value = ix->st_host_direct;
+    else if (!strcmp(name, "fused")) *value = ix->st_fused;
     else if (!strcmp(name, "cand_cap")) *value = HDB_CAND_CAP;
     else if (!strcmp(name, "n")) *value = ix->n;
     else if (!strcmp(name, "ws_bytes")) *value = (int64_t)ix->ws_bytes;
@@ -534,10 +546,13 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     unsigned long long* cand = b.take<unsigned long long>((size_t)cq_max * HDB_CAND_CAP);
     float* sbuf = b.take<float>((size_t)cq_max * (exact && !small ? ld_n : ld_s));
 
+    // 1-4 dot / cosine queries, k <= 128, fp16 matrix: one launch does everything (no prep kernel either)
+    const bool fused = mfma && ix->use_fused && !exact && !small && !full_sort && m == 8 && dev_status != nullptr &&
+                       hdb_mfma_fused_supported(ix->dtype, ix->d, metric, nq, kk);
     // the MFMA scan multiplies with fp16 queries: written by the same kernel (pearson converts its centred copy later)
     const bool f16_queries = mfma && ix->dtype == HDB_F16;          // fp32 matrices multiply with the float32 queries as they are
     const bool q16_in_prep = f16_queries && !is_pearson && !full_sort;
-    LAUNCH_TRY(hdb_launch_qprep(dev_Q, nq, ix->d, f64, qinv, qsq, qnan, q16_in_prep ? q16 : nullptr, qscl, st));
+    if (!fused) LAUNCH_TRY(hdb_launch_qprep(dev_Q, nq, ix->d, f64, qinv, qsq, qnan, q16_in_prep ? q16 : nullptr, qscl, st));
     if (is_ham) {
         rc = ensure_bits(ix, st); if (rc) return rc;
         LAUNCH_TRY(hdb_launch_qsign(dev_Q, nq, ix->d, f64, W, qbits, st));
@@ -594,6 +609,33 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
         }
         LAUNCH_TRY(hdb_launch_maskbias(ix->mask, ix->bias, n, ix->mbias, st));
         bias_eff = ix->mbias; mask_eff = nullptr;
+    }
+    ix->st_fused = 0;
+    if (fused) {
+        // ---- the whole call in ONE launch (hdb_mfma_fused.h): prep + sample + threshold + filter pass + finalize ----
+        if (!ix->fctl) {
+            const size_t cb = hdb_mfma_fused_ctl_bytes();
+            HIP_TRY(hipMalloc((void**)&ix->fctl, cb));
+            HIP_TRY(hipMemset(ix->fctl, 0, cb));
+        }
+        ScanArgs a; base_args(ix, a, dev_Q, metric);
+        a.bias = bias_eff; a.mask = nullptr;
+        a.ntiles = (n + tile_rows - 1) / tile_rows;
+        a.thr = thr; a.cnt = cnt; a.cand = cand; a.nq = nq;
+        FusedArgs fa; memset(&fa, 0, sizeof(fa));
+        fa.Qraw = static_cast<const float*>(dev_Q); fa.nq = nq;
+        fa.s_tiles = s_tiles; fa.s_stride = s_stride;
+        if (++ix->fused_epoch == 0) ix->fused_epoch = 1;
+        fa.epoch = ix->fused_epoch;
+        fa.timeout_ticks = (uint32_t)std::min<int64_t>(ix->fused_timeout_us * 100, 0x7FFFFFFF);
+        fa.ctl = reinterpret_cast<uint32_t*>(ix->fctl);
+        fa.cand = cand; fa.cap = HDB_CAND_CAP; fa.k = (uint32_t)k; fa.kk = kk; fa.row_base = ix->row_base;
+        fa.idx_out = dev_idx; fa.score_out = dev_score; fa.status = dev_status; fa.thr_out = thr;
+        ix->st_sample_rows = s_rows; ix->st_sample_m = m; ix->st_chunks = 1; ix->st_path = 1; ix->st_mfma = 1; ix->st_fused = 1;
+        prof_begin(ix, st);
+        LAUNCH_TRY(hdb_launch_mfma_fused(&a, &fa, (int)ix->max_blocks, st));
+        prof_end(ix, st);
+        return HDB_OK;
     }
     bool q16_ready = q16_in_prep;
     ix->st_sample_rows = s_rows; ix->st_sample_m = m; ix->st_chunks = 0;
@@ -891,6 +933,11 @@ extern "C" int hdb_group_create(hdb_group** out, hdb_index* const* shards, int32
     if (e == hipSuccess) e = hipSetDevice(g->merge_dev);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->merge_st, hipStreamNonBlocking);
     if (e != hipSuccess) { hdb_group_destroy(g); return fail(HDB_ERR_HIP, std::string("hdb_group_create: ") + hipGetErrorString(e)); }
+    // Two shards on ONE device would launch two single-launch pipelines at once, each wanting every CU for its in-kernel
+    // exchange: they could block each other until the spin timeout.  Such shards (a test layout) use the multi-kernel pipeline.
+    for (int p = 0; p < parts; ++p)
+        for (int r = 0; r < parts; ++r)
+            if (r != p && g->ix[r]->device == g->ix[p]->device) g->ix[p]->use_fused = 0;
     for (int p = 0; p < parts; ++p) g->th.emplace_back(group_worker, g, p);
     *out = g;
     return HDB_OK;

@@ -42,6 +42,22 @@ struct ScanArgs {
     int32_t raw;            // 1: keep NaN scores as NaN (per-metric functions); 0: NaN -> -inf (ranking)
 };
 
+// Extra arguments of the single-launch top-k (hdb_mfma_fused.h): sample plan, exchange block, outputs.
+struct FusedArgs {
+    const float* Qraw;              // [nq][d] float32 queries as the caller passed them
+    int32_t nq;
+    int64_t s_tiles, s_stride;      // phase A: strided sample (tiles of R rows)
+    uint32_t epoch;                 // != 0, different for every launch on this control block
+    uint32_t timeout_ticks;         // s_memrealtime ticks (100 MHz) a spin may last
+    uint32_t* ctl;                  // [0] done counter, [1] abort word, [2..5] candidate counters, zero between calls
+    unsigned long long* gran;       // [grid][32] granules
+    unsigned long long* cand;       // [nq][cap]
+    uint32_t cap, k, kk;
+    int64_t row_base;
+    int64_t* idx_out; float* score_out; int32_t* status;
+    float* thr_out;                 // [nq] thresholds (diagnostics)
+};
+
 // ---- fp16 copy of a query for the matrix pipe ----------------------------------------------------------
 // Power-of-two scale that puts the largest magnitude of a query in [2^14, 2^15): an fp32 element above 65504 would
 // otherwise become inf in fp16 and one below 6e-5 a subnormal.  Exact, and undone for free in the kernel epilogue

@@ -1,0 +1,35 @@
+// hdb_mfma_fused.hip -- instantiations of the single-launch top-k (hdb_mfma_fused.h) for the fp16 geometries of
+// hdb_mfma.hip: a whole hdb_topk call of 1..4 dot / cosine queries in ONE kernel.
+#include "hdb_mfma_fused.h"
+
+extern "C" int hdb_mfma_tile_rows(int dtype, int d);
+
+extern "C" int hdb_mfma_fused_supported(int dtype, int d, int metric, int nq, uint32_t kk) {
+    // d <= 768: beyond that the query fragments (d/8 registers) leave no room for the selectors' state without spilling
+    return dtype == HDB_F16 && hdb_mfma_tile_rows(dtype, d) > 0 && d <= 768 && (metric == HDB_DOT || metric == HDB_COSINE) &&
+           nq >= 1 && nq <= HDB_FUSED_MAXQ && kk <= 128;
+}
+
+// bytes of the persistent control block: 64 words of counters + the granules
+extern "C" size_t hdb_mfma_fused_ctl_bytes(void) { return 256 + (size_t)HDB_FUSED_MAX_WG * HDB_FUSED_GRAN_PER_WG * 8; }
+
+extern "C" int hdb_launch_mfma_fused(const ScanArgs* args, const FusedArgs* fa, int max_blocks, void* stream) {
+    const ScanArgs& a = *args;
+    FusedArgs f = *fa;
+    hipStream_t st = (hipStream_t)stream;
+    const int cus = hdb_cu_count();
+    int blocks = (int)(a.ntiles < cus ? a.ntiles : cus);
+    if (max_blocks > 0 && max_blocks < blocks) blocks = max_blocks;
+    if (blocks > HDB_FUSED_MAX_WG) blocks = HDB_FUSED_MAX_WG;
+    if (blocks < 1) blocks = 1;
+    f.gran = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(f.ctl) + 256);
+    switch (a.d) {
+        case 128: return launch_fused<128, 64>(a, f, blocks, st);
+        case 256: return launch_fused<256, 64>(a, f, blocks, st);
+        case 384: return launch_fused<384, 64>(a, f, blocks, st);
+        case 512: return launch_fused<512, 32>(a, f, blocks, st);
+        case 640: return launch_fused<640, 32>(a, f, blocks, st);
+        case 768: return launch_fused<768, 32>(a, f, blocks, st);
+        default: return (int)hipErrorNotSupported;
+    }
+}

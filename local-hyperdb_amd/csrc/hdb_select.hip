@@ -18,6 +18,7 @@
 // prefix from hist[q][0..pass) in its prologue, so kernel boundaries provide all the ordering.
 #include "hdb_common.h"
 #include "../../include/hyperdb_hip.h"
+#include "hdb_finalize.h"
 
 // hist layout: [nq][4][256] uint32
 struct Prefix { uint32_t key; uint32_t need; uint32_t bin_count; };
@@ -257,140 +258,16 @@ __global__ __launch_bounds__(1024) void hdb_ties_seq_kernel(const float* scores,
 }
 
 // ------------------------------------------------------------------------------------------------
-// Finalize: sort the candidate list of one query (<= HDB_CAND_CAP packed entries) descending and
-// emit the first k.  1024 threads, 64 KiB of LDS.
+// Finalize kernel: one workgroup per query (body in hdb_finalize.h).  1024 threads, 136 KiB of LDS.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void hdb_bitonic_desc(unsigned long long* buf, int P) {
-    for (int size = 2; size <= P; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = threadIdx.x; t < (P >> 1); t += blockDim.x) {
-                const int i = ((t / stride) * (stride << 1)) + (t % stride);
-                const int j = i + stride;
-                const bool desc = (i & size) == 0;
-                const unsigned long long x = buf[i], y = buf[j];
-                if (desc ? (x < y) : (x > y)) { buf[i] = y; buf[j] = x; }
-            }
-            __syncthreads();
-        }
-    }
-}
-
-// Pre-selection for finalize/merge: keeps (in buf[0..ns)) a superset of the kk largest of buf[0..nc) that is
-// usually only a little larger than kk, so that the O(log^2) bitonic network runs on ~256 instead of ~4096
-// entries.  Monotone linear binning of the 32-bit score key into 2048 bins between the smallest and the
-// largest key present; everything in or above the bin holding the kk-th largest survives.  Exactness is
-// untouched: the survivors always contain the true top-kk, ties included.  Returns ns (>= min(kk, nc)).
-// hist: 2048 words of LDS; scratch: nc u64 of LDS (may alias nothing else).
-__device__ uint32_t hdb_preselect(unsigned long long* buf, uint32_t nc, uint32_t kk, uint32_t* hist,
-                                  unsigned long long* scratch, uint32_t* ctl /* 8 words */) {
-    const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nth >> 6;
-    constexpr uint32_t NB = 2048;
-    // min / max key
-    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
-    for (uint32_t i = tid; i < nc; i += nth) { const uint32_t k = (uint32_t)(buf[i] >> 32); kmin = min(kmin, k); kmax = max(kmax, k); }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o, 64)); kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o, 64)); }
-    if (tid < 8) ctl[tid] = tid == 0 ? 0xFFFFFFFFu : 0u;
-    for (uint32_t i = tid; i < NB; i += nth) hist[i] = 0;
-    __syncthreads();
-    if (lane == 0) { atomicMin(&ctl[0], kmin); atomicMax(&ctl[1], kmax); }
-    __syncthreads();
-    kmin = ctl[0]; kmax = ctl[1];
-    const unsigned long long span = (unsigned long long)(kmax - kmin) + 1ull;
-    auto bin_of = [&](uint32_t k) { return (uint32_t)(((unsigned long long)(k - kmin) * NB) / span); };
-    for (uint32_t i = tid; i < nc; i += nth) atomicAdd(&hist[bin_of((uint32_t)(buf[i] >> 32))], 1u);
-    __syncthreads();
-    // suffix scan from the top bin: thread t owns bins NB-1-2t, NB-2-2t (1024 threads) -- generic stride
-    const uint32_t per = (NB + nth - 1) / nth;
-    uint32_t loc[8]; uint32_t tot = 0;              // per <= 8 (blockDim >= 256)
-    for (uint32_t j = 0; j < per; ++j) { const uint32_t b = tid * per + j; loc[j] = b < NB ? hist[NB - 1 - b] : 0; tot += loc[j]; }
-    uint32_t incl = tot;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
-    uint32_t* wsum = hist;      // reuse after everyone has read its bins
-    __syncthreads();
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    uint32_t before = incl - tot;
-    for (int w2 = 0; w2 < wave; ++w2) before += wsum[w2];
-    for (uint32_t j = 0; j < per; ++j) {
-        if (before < kk && kk <= before + loc[j]) ctl[2] = NB - 1 - (tid * per + j);     // the bin holding the kk-th largest
-        before += loc[j];
-    }
-    __syncthreads();
-    const uint32_t bsel = ctl[2];
-    // compact survivors
-    for (uint32_t i = tid; i < nc; i += nth) {
-        const unsigned long long e = buf[i];
-        if (bin_of((uint32_t)(e >> 32)) >= bsel) scratch[atomicAdd(&ctl[3], 1u)] = e;
-    }
-    __syncthreads();
-    const uint32_t ns = ctl[3];
-    for (uint32_t i = tid; i < ns; i += nth) buf[i] = scratch[i];
-    __syncthreads();
-    (void)nwaves;
-    return ns;
-}
-
-// LDS carve for finalize/merge: buf (cap u64) | scratch (cap u64) | hist (2048 u32) | ctl (8 u32)
 __global__ __launch_bounds__(1024) void hdb_finalize_kernel(const unsigned long long* cand, const uint32_t* cnt,
                                                             uint32_t cap, uint32_t k, uint32_t kk /* min(k, n) */,
                                                             int64_t row_base, int64_t* idx_out, float* score_out,
                                                             int32_t* status, const int* qnan) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long buf[];
-    unsigned long long* scratch = buf + cap;
-    uint32_t* hist = reinterpret_cast<uint32_t*>(scratch + cap);
-    uint32_t* ctl = hist + 2048;
     const int q = blockIdx.x;
-    const uint32_t total = cnt[q];
-    const uint32_t nc = total < cap ? total : cap;
-    for (uint32_t i = threadIdx.x; i < nc; i += blockDim.x) buf[i] = cand[(int64_t)q * cap + i];
-    __syncthreads();
-    uint32_t ns = nc;
-    if (nc > 512 && kk < nc / 2) ns = hdb_preselect(buf, nc, kk, hist, scratch, ctl);
-    const uint32_t nout = nc < kk ? nc : kk;             // entries that exist
-    if (ns <= 256) {
-        // Few survivors (the usual case: ~kk plus one histogram bin): rank sort.  Packed entries are distinct, so the
-        // number of larger entries is the output position; one pass of LDS broadcast reads, no barrier.
-        for (uint32_t i = nout + threadIdx.x; i < k; i += blockDim.x) { idx_out[(int64_t)q * k + i] = -1; score_out[(int64_t)q * k + i] = -INFINITY; }
-        if (threadIdx.x < ns) {
-            const unsigned long long mine = buf[threadIdx.x];
-            uint32_t rank = 0;
-            uint32_t j = 0;
-            for (; j + 2 <= ns; j += 2) {
-                const ulonglong2 pr = *reinterpret_cast<const ulonglong2*>(buf + j);
-                rank += (pr.x > mine) + (pr.y > mine);
-            }
-            if (j < ns) rank += buf[j] > mine;
-            if (rank < nout) {
-                idx_out[(int64_t)q * k + rank] = row_base + (int64_t)(0xFFFFFFFFu - (uint32_t)(mine & 0xFFFFFFFFull));
-                score_out[(int64_t)q * k + rank] = hdb_key2f((uint32_t)(mine >> 32));
-            }
-        }
-    } else {
-    int P = 64;
-    while ((uint32_t)P < ns) P <<= 1;
-    for (int i = ns + threadIdx.x; i < P; i += blockDim.x) buf[i] = 0ull;
-    __syncthreads();
-    hdb_bitonic_desc(buf, P);
-    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
-        if (i < nc && i < kk) {
-            const unsigned long long e = buf[i];
-            idx_out[(int64_t)q * k + i] = row_base + (int64_t)(0xFFFFFFFFu - (uint32_t)(e & 0xFFFFFFFFull));
-            score_out[(int64_t)q * k + i] = hdb_key2f((uint32_t)(e >> 32));
-        } else {
-            idx_out[(int64_t)q * k + i] = -1;
-            score_out[(int64_t)q * k + i] = -INFINITY;
-        }
-    }
-    }
-    if (threadIdx.x == 0 && status) {
-        int32_t st = 0;
-        if (total > cap) st |= HDB_Q_OVERFLOW;
-        if (nc < kk) st |= HDB_Q_UNDERFLOW;
-        if (qnan && qnan[q]) st |= HDB_Q_NAN;
-        status[q] = st;
-    }
+    hdb_finalize_body(buf, cand + (int64_t)q * cap, cnt[q], q, cap, k, kk, row_base, idx_out, score_out, status,
+                      qnan ? qnan[q] : 0, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
