@@ -49,7 +49,7 @@ struct FusedArgs {
     int64_t s_tiles, s_stride;      // phase A: strided sample (tiles of R rows)
     uint32_t epoch;                 // != 0, different for every launch on this control block
     uint32_t timeout_ticks;         // s_memrealtime ticks (100 MHz) a spin may last
-    uint32_t* ctl;                  // [0] done counter, [1] abort word, [2..5] candidate counters, zero between calls
+    uint32_t* ctl;                  // [0] done counter, [1] abort word, [2..5] candidate counters, [32] tile counter (own cache line): zero between calls
     unsigned long long* gran;       // [grid][32] granules
     unsigned long long* cand;       // [nq][cap]
     uint32_t cap, k, kk;

@@ -4,6 +4,9 @@
 // filter scan -> finalize, ~45 us of fixed cost of which ~17 us are queue gaps between the launches).  The reference
 // does all of it in one Python call per query (hyperdb/ranking_algorithm.py:149-204).
 //
+// Roles of the eight waves (a wave that blocks on an exchange must not also be on the staging path):
+//   wave 0 multiplies and filters; waves 1-2 are the selectors (two queries each); wave 3 requests tile chunks from the
+//   global counter; waves 4-7 stage the tiles (LDS-DMA, 2*NG pieces of 1 KiB each per tile) and the per-row aux values.
 // Structure (persistent, one 512-thread workgroup per CU, the LDS ring of hdb_mfma_kernel.h):
 //   prologue  every workgroup converts the float32 queries itself (fp16 copies scaled by a power of two into LDS,
 //             1/||q||, NaN flag): 4 x d elements, cheaper than a launch.
@@ -28,6 +31,20 @@
 #pragma once
 #include "hdb_mfma_kernel.h"
 #include "hdb_finalize.h"
+
+// Diagnostic build only (tools/stamps_fused.py; product: 0): wall-clock stamps (s_memrealtime, 100 MHz) of the phases
+// of every workgroup, stored in a buffer of their own that nothing reads: [wg][8] = start, prologue done, published,
+// threshold known, loop done, ticket taken, finalize done (last workgroup only), spare.
+#define HDB_CLOCK_WGS_F 1024
+#ifndef HDB_FUSED_STAMPS
+#define HDB_FUSED_STAMPS 0
+#endif
+#if HDB_FUSED_STAMPS
+static __device__ unsigned long long hdb_fused_stamps[8 * HDB_CLOCK_WGS_F];
+#define HDB_STAMP(slot) do { if (lane == 0 && stamp_wave) hdb_fused_stamps[8 * blockIdx.x + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define HDB_STAMP(slot) do { } while (0)
+#endif
 
 #define HDB_FUSED_MAXQ 4            // queries per fused call
 #define HDB_FUSED_M 8               // sample order statistic (k <= 128)
@@ -69,8 +86,9 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     constexpr int STAGE = R * ROWB;
     constexpr int NG = R * CPR / 64 / 8;
     constexpr bool AUX0 = METRIC != 0;
-    constexpr int NLOADA = NG;
-    constexpr int NLOADB = NG + (AUX0 ? 1 : 0) + (HAS_BIAS ? 1 : 0);
+    constexpr int NGL = 2 * NG;                 // pieces per staging wave and tile (waves 4-7)
+    constexpr int NLOADA = NGL;
+    constexpr int NLOADB = NGL + (AUX0 ? 1 : 0) + (HAS_BIAS ? 1 : 0);
     constexpr int M = HDB_FUSED_M;
     static_assert(R % MF == 0 && R <= 64 && (R * CPR) % 512 == 0 && ROWB % 256 == 0, "tile geometry");
     static_assert(METRIC == 0 || METRIC == 1, "dot / cosine");
@@ -89,48 +107,96 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     const int rl = lane & (MF - 1);
     const int h = lane / MF;
     const int nq = f.nq;
-    const bool grpB = w >= 4;
+    const bool loader = w >= 4;                     // waves 4-7 stage the tiles
+    const bool grpB = w >= 6;                       // ... 6-7 also the per-row aux values
+    const int lw = w & 3;
     const bool mfma_wave = w == 0;                  // nq <= 16: one wave multiplies, the kernel is a streaming kernel
-    const bool selector = w >= 1 && w <= nq;        // wave q+1 keeps the top-M sample scores of query q
+    const bool selector = (w == 1 || w == 2) && 2 * (w - 1) < nq;   // wave 1: queries 0-1, wave 2: queries 2-3
+    const bool requester = w == 3;
     const int64_t G = gridDim.x;
     const int64_t b = blockIdx.x;
 
     if (tid < 16) ctl[tid] = 0;
+#if HDB_FUSED_STAMPS
+    bool stamp_wave = w == 0;
+#endif
+    HDB_STAMP(0);
 
     // ---- tile sequence: phase A (sample) then phase B (all rows) through ONE ring ------------------
     const char* const Vb = reinterpret_cast<const char*>(a.V);
     const int64_t n_rows = a.n;
     const int64_t nA = f.s_tiles > b ? (f.s_tiles - b + G - 1) / G : 0;
-    const int64_t nB = a.ntiles > b ? (a.ntiles - b + G - 1) / G : 0;
-    const int64_t total = nA + nB;
-    auto row0_of = [&](int64_t i) -> int64_t {
-        return i < nA ? hdb_tile_index(b + i * G, f.s_stride) * R : (b + (i - nA) * G) * (int64_t)R;
+    // Phase B hands out its tiles DYNAMICALLY, in chunks of CH consecutive tiles: the first S chunks of a workgroup are
+    // fixed (chunk c -> tiles (c*G + b)*CH ...), every later one comes from a global counter (f.ctl[32], a cache line
+    // of its own: ~35 requests per us at N = 10M).  With a static split the slowest workgroup finished 15-25 us after the
+    // median one (N = 1.25M .. 10M): that tail is what the counter removes.  Wave 3 requests the chunks and hands the
+    // answers over through LDS.
+    const int64_t CH = a.ntiles >= 32 * G ? 4 : 1;   // size of the fixed chunks (and of the large requests)
+    const int64_t S = CH == 1 ? 3 : 1;
+    const int64_t ntiles = a.ntiles;
+    const int64_t dyn0 = S * G * CH;                 // first tile handed out by the counter
+    unsigned int* dq = ctl + 4;                      // [2][2] {first tile - dyn0, length} handed over by wave 7
+    const unsigned int dq_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(dq);
+    int64_t gp = 0;                                  // next sequence position to generate
+    int64_t cidx = 0, coff = 0, cbase = 0, clen = CH;   // phase-B generator: chunk number, offset in it, its first tile, its length
+    int64_t seen = 0;                                // requester: the counter after its last request
+    // -> row0 of sequence position gp (and whether it exists); positions < nA are the sample tiles
+    auto gen = [&](int64_t& row0, bool& valid) {
+        if (gp < nA) {
+            row0 = hdb_tile_index(b + gp * G, f.s_stride) * R; valid = true;
+        } else {
+            if (coff == 0) {
+                if (cidx < S) { cbase = (cidx * G + b) * CH; clen = CH; }
+                else {
+                    unsigned long long pr;
+                    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(pr) : "v"(dq_addr + (unsigned int)(cidx & 1) * 8u) : "memory");
+                    cbase = dyn0 + (int64_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)pr);
+                    clen = (int64_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(pr >> 32));
+                }
+            }
+            // Request the chunk after this one two rounds before its first tile is generated (the counter answers within a
+            // round): a workgroup then never holds more than the chunk it works on, which bounds the finishing skew.
+            if (requester && coff == (clen >= 2 ? clen - 2 : 0) && cidx + 1 >= S) {
+                // 4 tiles per request while plenty are left, 2 for the last ~6 rounds of the grid: the slowest workgroups
+                // stream ~25 % slower than the fastest, and what they still hold when the counter runs dry is the tail
+                const unsigned int want = CH == 1 ? 1u : (ntiles - dyn0 - seen > 6 * G ? (unsigned int)CH : 2u);
+                unsigned int got = 0u;
+                if (lane == 0) got = __hip_atomic_fetch_add(f.ctl + 32, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                got = (unsigned int)__builtin_amdgcn_readfirstlane((int)got);
+                seen = (int64_t)got + want;
+                const unsigned long long pr = ((unsigned long long)want << 32) | got;
+                if (lane == 0) asm volatile("ds_write_b64 %0, %1" :: "v"(dq_addr + (unsigned int)((cidx + 1) & 1) * 8u), "v"(pr) : "memory");
+            }
+            const int64_t t = cbase + coff;
+            valid = t < ntiles; row0 = t * (int64_t)R;
+            if (++coff == clen) { coff = 0; ++cidx; }
+        }
+        ++gp;
     };
-
-    int g_off[NG];
+    int g_off[NGL];
 #pragma unroll
-    for (int j = 0; j < NG; ++j) {
-        const int slot = (w + 8 * j) * 64 + lane;
+    for (int j = 0; j < NGL; ++j) {
+        const int slot = (lw + 4 * j) * 64 + lane;
         const int r = slot / CPR, cpos = slot - r * CPR;
         g_off[j] = r * ROWB + (cpos ^ (r & 15)) * 16;
     }
-    auto issue = [&](int64_t i, int st) {
-        const int64_t row0 = row0_of(i);
+    auto issue = [&](int64_t row0, int st) {
+        if (!loader) return;
         const int64_t last = n_rows - 1 - row0;
         char* sdst = smem + st * STAGE;
         const char* tile_base = Vb + row0 * (int64_t)ROWB;
         if (last >= R - 1) {
 #pragma unroll
-            for (int j = 0; j < NG; ++j)
+            for (int j = 0; j < NGL; ++j)
                 __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(tile_base + (unsigned int)g_off[j]),
-                                                 HDB_LDS_PTR(sdst + (w + 8 * j) * 1024), 16, 0, 2);
+                                                 HDB_LDS_PTR(sdst + (lw + 4 * j) * 1024), 16, 0, 2);
         } else {
 #pragma unroll
-            for (int j = 0; j < NG; ++j) {
+            for (int j = 0; j < NGL; ++j) {
                 const int r = g_off[j] / ROWB;
                 const int rr = r <= (int)last ? r : (int)last;
                 const unsigned int off = (unsigned int)(g_off[j] + (rr - r) * ROWB);
-                __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(tile_base + off), HDB_LDS_PTR(sdst + (w + 8 * j) * 1024), 16, 0, 2);
+                __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(tile_base + off), HDB_LDS_PTR(sdst + (lw + 4 * j) * 1024), 16, 0, 2);
             }
         }
         if ((AUX0 || HAS_BIAS) && grpB) {
@@ -148,8 +214,11 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
 #pragma unroll
         for (int u = 0; u < QPL; ++u) { const int e = lane + 64 * u; qreg[u] = e < D ? qv[e] : 0.f; }
     }
-    if (total > 0) issue(0, 0);
-    if (total > 1) issue(1, 1);
+    int64_t rA, rB, rC = 0; bool vA, vB, vC = false;      // rows / existence of sequence positions p, p+1, p+2
+    gen(rA, vA);
+    gen(rB, vB);
+    if (vA) issue(rA, 0);
+    if (vB) issue(rB, 1);
     const unsigned int tsc_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(tsc);
     const unsigned int qpar_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(qpar);
     const unsigned int qlds_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(qlds);
@@ -173,6 +242,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
         }
     }
     hdb_lds_barrier();
+    HDB_STAMP(1);
 
     // ---- wave 0: B fragments and per-query constants ---------------------------------------------
     const bool q_ok = rl < nq;
@@ -202,14 +272,35 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     const unsigned int rd_base = (unsigned int)(rl * CPR * 16);
     const unsigned int hx = (unsigned int)((h ^ (rl & 15)) << 4);
 
+    // LDS candidate list -> global lists.  ONE global atomic per query and flush reserves the slots of all its entries
+    // (ranks inside the workgroup come from LDS atomics): every workgroup finishes within a few us of the others, and an
+    // atomic per entry on the one counter word of a single query (2048 of them at ~88 per us) held the end of the kernel
+    // up by 20 us.
     auto flush = [&]() {
         hdb_lds_barrier();
         const unsigned int ne = ctl[0] < HDB_MFMA_CB ? ctl[0] : HDB_MFMA_CB;
-        for (unsigned int e = tid; e < ne; e += 512) {
-            const unsigned long long ent = cb[e];
-            const unsigned int qe = cbq[e];
-            const unsigned int pos = atomicAdd(&f.ctl[2 + qe], 1u);
-            if (pos < f.cap) f.cand[(int64_t)qe * f.cap + pos] = ent;
+        if (tid < 8) ctl[8 + tid] = 0;               // [8..11] entries per query, [12..15] their first global slot
+        hdb_lds_barrier();
+        unsigned int rank[HDB_MFMA_CB / 512];
+#pragma unroll
+        for (int u = 0; u < HDB_MFMA_CB / 512; ++u) {
+            const unsigned int e = tid + 512 * u;
+            rank[u] = e < ne ? atomicAdd(&ctl[8 + cbq[e]], 1u) : 0u;
+        }
+        hdb_lds_barrier();
+        if (tid < HDB_FUSED_MAXQ) {
+            const unsigned int c = ctl[8 + tid];
+            ctl[12 + tid] = c ? atomicAdd(&f.ctl[2 + tid], c) : 0u;
+        }
+        hdb_lds_barrier();
+#pragma unroll
+        for (int u = 0; u < HDB_MFMA_CB / 512; ++u) {
+            const unsigned int e = tid + 512 * u;
+            if (e < ne) {
+                const unsigned int qe = cbq[e];
+                const unsigned int pos = ctl[12 + qe] + rank[u];
+                if (pos < f.cap) f.cand[(int64_t)qe * f.cap + pos] = cb[e];
+            }
         }
         hdb_lds_barrier();
         if (tid == 0) ctl[0] = 0;
@@ -255,8 +346,11 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     };
 
     // ---- selector state: the M largest sample scores of this wave's query, as orderable keys, lane r < M holds one
-    uint32_t keep = 0u;                              // key 0 sorts below every float, -inf included
-    auto merge_tile = [&](unsigned int src64_addr) {      // 64 new scores, one per lane
+    uint32_t keep[2] = {0u, 0u};                     // key 0 sorts below every float, -inf included
+    bool thr_final[2] = {false, false};              // every workgroup's sample went into this query's threshold
+    bool gave_up = false;
+    unsigned long long sweep_t0 = 0ull;
+    auto merge_tile = [&](uint32_t& keep, unsigned int src64_addr) {      // 64 new scores, one per lane
         uint32_t cur = hdb_f2key(hdb_canon(hdb_lds_ld32(src64_addr + (unsigned int)lane * 4u)));
         uint32_t out = 0u;
 #pragma unroll
@@ -280,92 +374,142 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     Acc acc[RT];
     int64_t row0_prev = 0;
     bool have_prev = false;                          // wave 0: acc holds an unfiltered phase-B tile
+    int thr_reads = 10;                              // wave 0 re-reads the threshold for the rounds in which sweeps can still raise it
     int st_cur = 0;
-    for (int64_t i = 0; i <= total; ++i) {           // one extra round (i == total) drains the deferred work
-        const bool tile = i < total;
-        if (tile) {
-            if (i + 1 >= total) hdb_wait_vmcnt<0>();
+    for (int64_t i = 0;; ++i) {                      // the round after the last tile drains the deferred work
+        const bool tile = vA;
+        if (tile && loader) {
+            if (!vB) hdb_wait_vmcnt<0>();
             else if (grpB) hdb_wait_vmcnt<NLOADB>();
             else hdb_wait_vmcnt<NLOADA>();
         }
         const bool chk = tile && i >= nA && ((i - nA) & chk_mask) == chk_mask;
         const int chk_slot = 1 + (int)(((i - nA) >> chk_shift) & 1);
         if (chk && tid == 0) ctl[chk_slot] = (ctl[0] >= HDB_MFMA_CB / 4) ? 1u : 0u;
-        hdb_lds_barrier();                           // tile i is in LDS; everyone is done with tile i-1; tsc/qpar hand-offs
+        hdb_lds_barrier();                           // tile i is in LDS; everyone is done with tile i-1; tsc/qpar/dq hand-offs
         const int st_next2 = st_cur == 0 ? 2 : st_cur - 1;
-        if (i + 2 < total) issue(i + 2, st_next2);
+        if (vB) gen(rC, vC); else vC = false;        // positions past the end are never generated (no stray requests)
+        if (vC) issue(rC, st_next2);
         if (chk && ctl[chk_slot]) flush();
 
-        // ---- selectors: sample bookkeeping, one tile behind wave 0 -----------------------------------
+        // ---- selectors: sample bookkeeping one tile behind wave 0, then the exchange ----------------------
+        // Any M-th largest over a SUBSET of the published sample values is a lower bound of the final threshold, so a
+        // sweep that finds only part of the granules tagged with this call's epoch already yields a safe (merely less
+        // selective) threshold: the filter pass starts on it and later sweeps raise it.  Nothing waits for the slowest
+        // workgroup, and a grid that is not fully resident cannot block (see the header).
         if (selector) {
-            const int q = w - 1;
-            if (i >= 1 && i <= nA) merge_tile(tsc_addr + (unsigned int)(((int)((i - 1) & 1) * HDB_FUSED_MAXQ + q) * 64) * 4u);
-            if (i == nA) {
-                // publish M granules {epoch, key}, then gather everybody's: the data is the flag (no barrier, no fence)
-                hdb_gu64* mine = (hdb_gu64*)(f.gran + (b * HDB_FUSED_GRAN_PER_WG + q * M));
-                if (lane < M) __hip_atomic_store(mine + lane, ((unsigned long long)f.epoch << 32) | keep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // lane l sweeps granule (l % M) of workgroups l / M, l / M + 8, ...
-                constexpr int WPL = 64 / M;                      // workgroups covered per sweep instruction
-                const int gi = lane % M, wg0 = lane / M;
-                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-                bool failed = false;
-                uint32_t top = 0u;
-                for (;;) {
-                    bool ok = true;
-                    uint32_t lmax[M];                            // per lane: the M largest of ITS granules (sorted desc)
 #pragma unroll
-                    for (int r = 0; r < M; ++r) lmax[r] = 0u;
-                    for (int64_t wg = wg0; wg < G; wg += WPL) {
-                        const unsigned long long x = __hip_atomic_load((hdb_gu64*)(f.gran + (wg * HDB_FUSED_GRAN_PER_WG + q * M + gi)),
-                                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        ok &= (uint32_t)(x >> 32) == f.epoch;
-                        uint32_t v = (uint32_t)x;
+            for (int qq = 0; qq < 2; ++qq) {
+                const int q = 2 * (w - 1) + qq;
+                if (q >= nq) continue;
+                if (i >= 1 && i <= nA) merge_tile(keep[qq], tsc_addr + (unsigned int)(((int)((i - 1) & 1) * HDB_FUSED_MAXQ + q) * 64) * 4u);
+                if (i == nA) {                       // publish M granules {epoch, key}: the data is the flag
+                    hdb_gu64* mine = (hdb_gu64*)(f.gran + (b * HDB_FUSED_GRAN_PER_WG + q * M));
+                    if (lane < M) __hip_atomic_store(mine + lane, ((unsigned long long)f.epoch << 32) | keep[qq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if HDB_FUSED_STAMPS
+                    stamp_wave = w == 1 && qq == 0;
+#endif
+                    HDB_STAMP(2);
+                    sweep_t0 = __builtin_amdgcn_s_memrealtime();
+                }
+            }
+            // first sweep right after publishing (repeated until usable), later attempts at rounds nA+3 and nA+7
+            const int64_t di = i - nA;
+            if (di == 0 || di == 3 || di == 7) {
 #pragma unroll
-                        for (int r = 0; r < M; ++r) { const uint32_t hi = max(lmax[r], v); v = min(lmax[r], v); lmax[r] = hi; }
-                    }
-                    if (__all(ok)) {
-                        // M rounds: the wave-wide maximum of the lane heads; its owner pops its head
-                        uint32_t kth = 0u;
+                for (int qq = 0; qq < 2; ++qq) {
+                    const int q = 2 * (w - 1) + qq;
+                    if (q >= nq || thr_final[qq] || gave_up) continue;
+                    constexpr int WPL = 64 / M;      // lane l sweeps granule (l % M) of workgroups l / M, l / M + WPL, ...
+                    const int gi = lane % M, wg0 = lane / M;
+                    // usable = at least 16 workgroups WITH sample rows have answered (their 8 x 16 best values put the
+                    // M-th largest at ~1 % of the rows: a few extra survivors for a round or two), or everybody has
+                    const int64_t samp_wgs = f.s_tiles < G ? f.s_tiles : G;
+                    const int need_wgs = (int)(samp_wgs < 16 ? samp_wgs : 16);
+                    for (;;) {
+                        bool ok = true;
+                        int nvalid = 0;
+                        uint32_t lmax[M];            // per lane: the M largest of ITS valid granules (sorted descending)
 #pragma unroll
-                        for (int r = 0; r < M; ++r) {
-                            uint32_t v = lmax[0];
+                        for (int r = 0; r < M; ++r) lmax[r] = 0u;
+                        constexpr int SB = 16;       // loads in flight per lane (two round trips at G = 256; 32 would spill at d = 768)
+                        for (int64_t base = wg0; base < G; base += SB * WPL) {
+                            unsigned long long x[SB];
 #pragma unroll
-                            for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
-                            const unsigned long long who = __ballot(lmax[0] == v);
-                            if (lane == (int)__ffsll((long long)who) - 1) {
-#pragma unroll
-                                for (int t = 0; t + 1 < M; ++t) lmax[t] = lmax[t + 1];
-                                lmax[M - 1] = 0u;
+                            for (int u = 0; u < SB; ++u) {
+                                const int64_t wg = base + u * WPL;
+                                x[u] = wg < G ? __hip_atomic_load((hdb_gu64*)(f.gran + (wg * HDB_FUSED_GRAN_PER_WG + q * M + gi)),
+                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                              : 0ull;    // tag 0 is never an epoch
                             }
-                            kth = v;
+#pragma unroll
+                            for (int u = 0; u < SB; ++u) {
+                                const bool tagged = (uint32_t)(x[u] >> 32) == f.epoch;
+                                uint32_t v = tagged ? (uint32_t)x[u] : 0u;
+                                if (base + u * WPL < G) { ok &= tagged; nvalid += v != 0u ? 1 : 0; }
+#pragma unroll
+                                for (int r = 0; r < M; ++r) { const uint32_t hi = max(lmax[r], v); v = min(lmax[r], v); lmax[r] = hi; }
+                            }
                         }
-                        top = kth;
-                        break;
+                        const bool all = __all(ok);
+                        // sample workgroups seen = tagged, non-empty granules of position 0 (the largest value of a workgroup)
+                        int cnt0 = gi == 0 ? nvalid : 0;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) cnt0 += __shfl_xor(cnt0, o, 64);
+                        if (all || cnt0 >= need_wgs) {
+                            uint32_t kth = 0u;       // M rounds: the wave-wide maximum of the lane heads; its owner pops its head
+#pragma unroll
+                            for (int r = 0; r < M; ++r) {
+                                uint32_t v = lmax[0];
+#pragma unroll
+                                for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
+                                const unsigned long long who = __ballot(lmax[0] == v);
+                                if (lane == (int)__ffsll((long long)who) - 1) {
+#pragma unroll
+                                    for (int t = 0; t + 1 < M; ++t) lmax[t] = lmax[t + 1];
+                                    lmax[M - 1] = 0u;
+                                }
+                                kth = v;
+                            }
+                            thr_final[qq] = all;
+                            if (di == 0) HDB_STAMP(3);
+                            if (lane == 0) {
+                                const float thr = kth == 0u ? -INFINITY : hdb_key2f(kth);
+                                hdb_lds_st32(qpar_addr + (unsigned int)(2 * HDB_FUSED_MAXQ + q) * 4u, thr);
+                                if (b == 0 && all) f.thr_out[q] = thr;
+                            }
+                            break;
+                        }
+                        if (spin_expired(sweep_t0)) {    // too few workgroups answered within the timeout: give up (host falls back)
+                            gave_up = true;
+                            if (lane == 0) {
+                                hdb_lds_st32(qpar_addr + (unsigned int)(2 * HDB_FUSED_MAXQ + q) * 4u, INFINITY);
+                                atomicOr(&f.ctl[1], 1u);
+                            }
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
                     }
-                    if (spin_expired(t0)) { failed = true; break; }
-                    __builtin_amdgcn_s_sleep(4);
                 }
-                if (lane == 0) {
-                    const float thr = failed ? INFINITY : (top == 0u ? -INFINITY : hdb_key2f(top));
-                    hdb_lds_st32(qpar_addr + (unsigned int)(2 * HDB_FUSED_MAXQ + q) * 4u, thr);
-                    if (b == 0) f.thr_out[q] = thr;
-                    if (failed) atomicOr(&f.ctl[1], 1u);
-                }
+#if HDB_FUSED_STAMPS
+                stamp_wave = false;
+#endif
             }
         }
 
         // ---- wave 0: multiply tile i; epilogue of a sample tile at once, of a filter tile one round later ----
         if (mfma_wave) {
             if (have_prev) {                         // deferred epilogue of tile i-1 (phase B)
-                if (i == nA + 1) {                   // published by the selectors before this round's barrier
+                if (thr_reads > 0) {                 // written by the selectors before this round's barrier; later sweeps raise it
                     const float t = hdb_lds_ld32(qpar_addr + (unsigned int)(2 * HDB_FUSED_MAXQ + (q_ok ? rl : 0)) * 4u);
                     thr_cmp = q_ok ? t : INFINITY;
+                    --thr_reads;
                 }
                 filter(acc, row0_prev);
                 have_prev = false;
             }
             if (tile) {
-                const int64_t row0 = row0_of(i);
+                const int64_t row0 = rA;
                 const unsigned int sb_addr = smem_addr + (unsigned int)(st_cur * STAGE) + rd_base;
                 constexpr int PF = 3;
                 Vec abuf[PF + 1][RT];
@@ -439,7 +583,13 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
             }
         }
         st_cur = st_cur == 2 ? 0 : st_cur + 1;
+        rA = rB; vA = vB; rB = rC; vB = vC;
+        if (!tile) break;
     }
+    HDB_STAMP(4);
+#if HDB_FUSED_STAMPS
+    if (tid == 0) hdb_fused_stamps[8 * blockIdx.x + 7] = (unsigned long long)(gp - nA);      // positions generated in phase B
+#endif
     flush();
 
     // ---- finish: drain, release, ticket; the last workgroup finalizes every query -------------------
@@ -455,6 +605,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+    HDB_STAMP(5);
     if (ctl[3]) {
         unsigned long long* fbuf = reinterpret_cast<unsigned long long*>(smem);     // the ring is free now
         const unsigned int aborted = __hip_atomic_load(f.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -469,7 +620,9 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                               f.status, (int)((qnan_bits >> q) & 1u), 0);
             __syncthreads();
         }
+        HDB_STAMP(6);
         if (tid < 2 + HDB_FUSED_MAXQ) __hip_atomic_store(f.ctl + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next call
+        if (tid == 32) __hip_atomic_store(f.ctl + 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -1,0 +1,59 @@
+"""Phase timeline of the single-launch top-k kernel (diagnostic build HDB_FUSED_STAMPS=1): where the fixed cost of a
+call goes.  build: needs hipcc; run: on an MI355X."""
+import json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, 'local-hyperdb_amd', 'csrc')
+OUT = os.path.join(ROOT, 'local-hyperdb_amd', 'lib', 'stamps')
+
+def build():
+    os.makedirs(OUT, exist_ok=True)
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objs = [os.path.join(CSRC, 'obj', f'{n}.o') for n in ('hdb_scan', 'hdb_select', 'hdb_mfma', 'hdb_mfma_f32', 'hdb_mfma_qt2', 'hdb_sort', 'hdb_rows', 'hdb_api')]
+    o = os.path.join(OUT, 'fused.o')
+    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-pass-failed', '-DHDB_FUSED_STAMPS=1',
+                           '-c', os.path.join(CSRC, 'hdb_mfma_fused.hip'), '-o', o])
+    subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', os.path.join(OUT, 'lib.so'), o] + objs)
+    os.remove(o)
+    print('built', os.path.join(OUT, 'lib.so'))
+
+def run():
+    os.environ['HYPERDB_HIP_LIB'] = os.path.join(OUT, 'lib.so')
+    sys.path.insert(0, os.path.join(ROOT, 'local-hyperdb_amd')); sys.path.insert(0, ROOT)
+    import ctypes, time
+    import numpy as np, torch
+    from hyperdb import _native
+    from hyperdb._native import GpuIndex, METRIC_IDS
+    import bench
+    dev = torch.device('cuda', 0)
+    lib = _native.lib()
+    lib.hdb_debug_read_fused_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    for n in (1_250_000, 10_000_000):
+        V, lo, hi = bench.make_shard(n, 384, torch.float16, 0, 1, dev)
+        ix = GpuIndex(V)
+        Q = bench.make_queries(64, 384, torch.float16, dev).to(torch.float32)
+        mid = METRIC_IDS['cosine_similarity']
+        rows = []
+        for i in range(40):
+            t0 = time.perf_counter(); ix.topk_views(Q[i:i + 1], 100, mid); wall = (time.perf_counter() - t0) * 1e6
+            if i < 10: continue
+            buf = (ctypes.c_uint64 * (8 * 256))()
+            lib.hdb_debug_read_fused_stamps(buf, 256)
+            a = np.frombuffer(buf, dtype=np.uint64).reshape(256, 8).astype(np.int64)
+            t_start = a[:, 0].min()
+            rel = (a - t_start) / 100.0          # us
+            last = int(np.argmax(a[:, 6]))
+            if i == 39:
+                order = np.argsort(rel[:, 4])
+                print('   per-WG loop-done percentiles (us):', [round(float(np.percentile(rel[:, 4], p)), 1) for p in (0, 10, 50, 90, 99, 100)],
+                      ' tiles generated min/med/max:', int(a[:, 7].min()), int(np.median(a[:, 7])), int(a[:, 7].max()),
+                      ' tiles of the 5 last finishers:', a[order[-5:], 7].tolist(), ' of the 5 first:', a[order[:5], 7].tolist(), flush=True)
+            rows.append([wall, rel[:, 0].max(), np.median(rel[:, 1]), np.median(rel[:, 2]), rel[:, 2].max(), np.median(rel[:, 3]), rel[:, 3].max(),
+                         np.median(rel[:, 4]), rel[:, 4].max(), rel[:, 5].max(), rel[last, 6]])
+        r = np.median(np.array(rows), axis=0)
+        names = ['host wall', 'last start', 'prologue done (med)', 'published (med)', 'published (max)', 'thr known (med)', 'thr known (max)',
+                 'loop done (med)', 'loop done (max)', 'ticket (max)', 'finalize done']
+        print(f"n={n}: " + ", ".join(f"{k} {v:.1f}" for k, v in zip(names, r)), flush=True)
+        ix.close(); del V; torch.cuda.empty_cache()
+
+if __name__ == '__main__':
+    {'build': build, 'run': run}[sys.argv[1]]()
