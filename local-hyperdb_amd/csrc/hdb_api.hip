@@ -315,7 +315,7 @@ extern "C" int hdb_index_set_row_mask(hdb_index* ix, const uint8_t* dev_mask) {
 
 extern "C" int hdb_set_option(hdb_index* ix, const char* name, int64_t value) {
     if (!ix || !name) return fail(HDB_ERR_ARG, "hdb_set_option: null argument");
-    if (!strcmp(name, "max_blocks")) ix->max_blocks = std::max<int64_t>(0, value);
+    if (!strcmp(name, "max_blocks")) ix->max_blocks = value;
     else if (!strcmp(name, "force_exact")) ix->force_exact = value;
     else if (!strcmp(name, "sample_target")) ix->sample_target = value;
     else if (!strcmp(name, "mfma_min_q")) ix->mfma_min_q = value;

@@ -116,8 +116,11 @@ extern "C" int hdb_launch_mfma_scan(const ScanArgs* args, int dtype, int mode, i
     const ScanArgs& a = *args;
     hipStream_t st = (hipStream_t)stream;
     if (a.mask) return (int)hipErrorNotSupported;
-    const int cus = hdb_cu_count();                      // one persistent workgroup per CU
-    int blocks = (int)(a.ntiles < cus ? a.ntiles : cus);
+    const int cus = hdb_cu_count();                      // one persistent workgroup per CU ...
+    // ... or, with max_blocks < 0, -max_blocks workgroups per CU: the hardware dispatcher then hands the next workgroup
+    // to whichever CU finishes first (CUs differ by up to 40 % in streaming speed, see hdb_mfma_fused.h)
+    const int64_t want = max_blocks < 0 ? (int64_t)cus * (-max_blocks) : cus;
+    int blocks = (int)(a.ntiles < want ? a.ntiles : want);
     if (max_blocks > 0 && max_blocks < blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
     if (dtype == HDB_F32) return hdb_launch_mfma_scan_f32(args, mode, nq_launch, q16, sqnorm, qsq, blocks, stream);

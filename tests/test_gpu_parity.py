@@ -1195,3 +1195,88 @@ def test_fuzz_gpu_against_oracle(orc):
         finally:
             ix.close()
     assert len({(m, t) for m, t, _, _ in seen}) == 21 and any(b for _, _, b, _ in seen) and any(f for _, _, _, f in seen)
+
+
+# ------------------------------------------------------------------------------------------------
+# 10. the single-launch pipeline (hdb_mfma_fused.h): 1-4 dot / cosine queries on fp16 matrices
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,d", [(8193, 384), (8200 + 63, 128), (50_000, 768), (400_000, 256), (1_300_001, 384)])
+def test_single_launch_pipeline_equals_multi_kernel_and_oracle(orc, n, d):
+    """Every call shape the fused kernel takes (1-4 queries, dot / cosine, k <= 128, bias, row mask, ragged last tile,
+    grids smaller than the CU count, static and counter-fed tile chunks) returns exactly what the five-kernel pipeline
+    and the on-device exact selection return; one case per shape is checked against the oracle's float64 scores."""
+    import torch
+    from hyperdb._native import GpuIndex, METRIC_IDS
+    rng = np.random.default_rng(n + d)
+    V = rng.standard_normal((n, d)).astype(np.float32).astype(np.float16)
+    V[n - 1] = V[7]                                        # duplicate rows across the matrix ends: tie -> lower row first
+    Q = rng.standard_normal((4, d)).astype(np.float16).astype(np.float32)
+    Q[1] = V[n // 3].astype(np.float32)
+    ix = GpuIndex(V)
+    try:
+        bias = torch.rand(n, generator=torch.Generator().manual_seed(3)).float().cuda() * 0.2
+        mask = (torch.rand(n, generator=torch.Generator().manual_seed(4)) < 0.3).to(torch.uint8).cuda()
+        for metric in ("cosine_similarity", "dot_product"):
+            mid = METRIC_IDS[metric]
+            for setup in ("plain", "bias", "mask", "mask+bias"):
+                ix.set_bias(bias if "bias" in setup else None)
+                ix.set_row_mask(mask if "mask" in setup else None)
+                for nq, k in ((1, 100), (2, 1), (3, 128), (4, 37)):
+                    ix.set_option("use_fused", 1)
+                    fi, fs, fst = ix.topk_device(Q[:nq], k, mid)
+                    assert ix.stat("fused") == 1 and ix.stat("path") == 1 and int(fst.abs().sum().item()) == 0, (metric, setup, nq, k)
+                    ix.set_option("use_fused", 0)
+                    ui, us, ust = ix.topk_device(Q[:nq], k, mid)
+                    assert ix.stat("fused") == 0
+                    ei, es, _ = ix.topk_device(Q[:nq], k, mid, exact=True)
+                    assert torch.equal(fi, ei) and torch.equal(fs, es), (metric, setup, nq, k)
+                    assert torch.equal(fi, ui) and torch.equal(fs, us), (metric, setup, nq, k)
+            ix.set_bias(None); ix.set_row_mask(None); ix.set_option("use_fused", 1)
+            idx, sc = ix.topk(Q[:2], 100, mid)
+            assert ix.stat("fused") == 1
+            for qi in range(2):
+                orc.check_topk(idx[qi], sc[qi], V, Q[qi], metric, 100, tol=1e-3)
+        # k > 128, five queries, euclidean: not the fused kernel's business
+        ix.topk_device(Q[:1], 200, METRIC_IDS["dot_product"]); assert ix.stat("fused") == 0
+        ix.topk_device(np.concatenate([Q, Q[:1]]), 10, METRIC_IDS["dot_product"]); assert ix.stat("fused") == 0
+        ix.topk_device(Q[:1], 10, METRIC_IDS["euclidean_metric"]); assert ix.stat("fused") == 0
+    finally:
+        ix.close()
+
+
+def test_single_launch_pipeline_failure_paths(ranking, orc):
+    """What must come back through the exact selection: a NaN query (status bit), massive ties that overflow the
+    candidate list, and an exchange that gives up (spin timeout forced to 10 ns) -- the caller still gets the right rows."""
+    import torch
+    from hyperdb._native import GpuIndex, METRIC_IDS, Q_NAN
+    rng = np.random.default_rng(99)
+    base = rng.standard_normal((40, 384)).astype(np.float32).astype(np.float16)
+    V = np.tile(base, (1500, 1))                           # 60k rows, every score repeated 1500 times
+    q = rng.standard_normal(384).astype(np.float16).astype(np.float32)
+    ix = GpuIndex(V)
+    try:
+        mid = METRIC_IDS["dot_product"]
+        idx, sc = ix.topk(q.reshape(1, -1), 100, mid)      # overflow -> hdb_topk_host re-runs the exact path
+        ex = orc.exact_scores(V, q, "dot_product")
+        want = np.nonzero(np.isclose(ex, ex.max(), rtol=1e-6))[0][:100]
+        assert np.array_equal(idx[0], want) and np.allclose(sc[0], ex.max(), rtol=1e-3)
+        qn = q.copy(); qn[5] = np.nan
+        _, _, st = ix.topk_device(np.stack([q, qn]), 10, mid)
+        assert ix.stat("fused") == 1 and (int(st[1].item()) & Q_NAN) and not (int(st[0].item()) & Q_NAN)
+    finally:
+        ix.close()
+    V2 = rng.standard_normal((300_000, 384)).astype(np.float32).astype(np.float16)
+    ix = GpuIndex(V2)
+    try:
+        mid = METRIC_IDS["cosine_similarity"]
+        ix.set_option("fused_timeout_us", 1)               # (the option floor; the kernel compares 100 MHz ticks)
+        fi, fs, st = ix.topk_device(q.reshape(1, -1), 50, mid)
+        gave_up = int(st[0].item()) != 0                   # on an idle GPU the first sweep may well succeed in time
+        idx, sc = ix.topk(q.reshape(1, -1), 50, mid)       # host entry: falls back when the kernel gave up
+        ix.set_option("fused_timeout_us", 2000)
+        ei, es, _ = ix.topk_device(q.reshape(1, -1), 50, mid, exact=True)
+        assert np.array_equal(idx[0], ei[0].cpu().numpy()) and np.array_equal(sc[0], es[0].cpu().numpy()), gave_up
+        fi, fs, st = ix.topk_device(q.reshape(1, -1), 50, mid)          # and the next call is clean again
+        assert int(st[0].item()) == 0 and torch.equal(fi, ei) and torch.equal(fs, es)
+    finally:
+        ix.close()
