@@ -33,6 +33,10 @@ static __device__ unsigned long long hdb_clock_buf[4 * HDB_CLOCK_WGS];
 //   2  B waves issue the first fragment reads of tile i BEFORE their deferred epilogue of tile i-1
 //   4  s_setprio 1 for waves 4-7 (the arbitration losers of each SIMD), once, before the tile loop
 //   8  s_setprio 1 for waves 0-3 instead
+// Shipped: 0.  Measured on N=10M d=384 Q=256, two interleaved rounds per variant (profiles/r2_q256_experiments.json):
+// 0: 1.908 ms, 1: 1.935, 2: 1.938, 3: 1.938, 4: 1.890, 5: 1.918, 7: 1.916, 8: 1.906, 9: 1.930 -- the re-orderings cost
+// (the chip gives saved issue cycles back as clock), and the 1 % of variant 4 did not hold on a second MI355X, where the
+// same build ran 1.914 ms against 1.772 ms with the survivor append knocked out (without the priority: 1.801 vs 1.795).
 #ifndef HDB_MFMA_EXP
 #define HDB_MFMA_EXP 0
 #endif
@@ -317,8 +321,8 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
         for (int qt = 0; qt < QT; ++qt) filter1(tv[qt], row0, thr_cmp[qt], qinv_l[qt], ql[qt]);
     };
 
-    if ((HDB_MFMA_EXP & 4) && grpB) __builtin_amdgcn_s_setprio(1);
-    if ((HDB_MFMA_EXP & 8) && !grpB) __builtin_amdgcn_s_setprio(1);
+    if ((HDB_MFMA_EXP & 4) && grpB && heavy) __builtin_amdgcn_s_setprio(1);     // only where the matrix pipe is the bottleneck
+    if ((HDB_MFMA_EXP & 8) && !grpB && heavy) __builtin_amdgcn_s_setprio(1);
     const int chk_shift = ntiles >= 65536 ? 4 : 0;
     const int64_t chk_mask = (1 << chk_shift) - 1;
 #if HDB_MFMA_CLOCK
