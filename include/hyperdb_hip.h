@@ -135,7 +135,10 @@ int hdb_scores(hdb_index* ix, const void* dev_q, int metric, float* dev_out, voi
  * float32 magnitude is safe) and float32 accumulation: nothing is lost when the query has the matrix's dtype, a
  * float32 query is rounded to 11 significant bits per element (score error ~1e-4 relative, inside the 1e-3
  * contract for fp16 data).  hdb_set_option(ix, "use_mfma", 0) keeps float32 queries unrounded (VALU scan).
- * float32 matrices (d in {128,256,384,512,768}) take batches of 5+ queries through fp32 MFMAs: exact fp32 products. */
+ * float32 matrices (d in {128,256,384,512,768}) take batches of 5+ queries through fp32 MFMAs: exact fp32 products.
+ * Calls of 1-4 dot / cosine queries with k <= 128 on an fp16 matrix (d <= 768) run as ONE kernel launch (query
+ * preparation, row sample, threshold exchange between the workgroups, filter pass, final sort: hdb_mfma_fused.h);
+ * everything else is the same pipeline as separate launches.  Results are identical either way. */
 int hdb_topk(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, int metric,
              int64_t* dev_idx, float* dev_score, int32_t* dev_status, void* stream);
 
@@ -192,8 +195,11 @@ void hdb_group_destroy(hdb_group* g);
  *   mfma_min_q (smallest batch that takes the MFMA scan on fp16 matrices, default 1), mfma_variant (16 | 32: MFMA
  *   shape of the 256-query pass), bits_fused (0: hamming / jaccard always through the exact selection),
  *   host_direct (0: hdb_topk_host always copies through a device record), exact_bytes (score workspace cap of
- *   the exact path), finalize_threads (256 | 512 | 1024), profile (1: HIP events around the pass over V).
- * Stats:    path (0 small, 1 sampled threshold, 2 exact, 3 full sort), mfma, host_direct, chunks, sample_rows, sample_m,
+ *   the exact path), finalize_threads (256 | 512 | 1024), profile (1: HIP events around the pass over V),
+ *   use_fused (0: never the single-launch pipeline), fused_timeout_us (bound of its in-kernel spins, default 2000),
+ *   host_poll (0: hdb_topk_host always waits on the stream instead of polling the status words of a pinned record).
+ *   max_blocks < 0 asks for -max_blocks workgroups per CU in the batched MFMA scan (measured: no gain).
+ * Stats:    path (0 small, 1 sampled threshold, 2 exact, 3 full sort), mfma, fused, host_direct, chunks, sample_rows, sample_m,
  *   scan_launches, scan_time_ns (sum over the profiled launches), cand_cap, n, ws_bytes. */
 int hdb_set_option(hdb_index* ix, const char* name, int64_t value);
 int hdb_get_stat(hdb_index* ix, const char* name, int64_t* value);

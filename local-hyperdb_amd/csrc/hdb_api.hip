@@ -16,6 +16,8 @@
 #include <cstdio>
 #include <algorithm>
 #include <vector>
+#include <chrono>
+#include <atomic>
 
 // launchers implemented in the kernel translation units
 extern "C" {
@@ -119,6 +121,7 @@ struct hdb_index {
     int64_t exact_bytes = (int64_t)1 << 30;
     int64_t bits_fused = 1;           // hamming / jaccard: try the sampled-threshold path first (exact path when it fails)
     int64_t host_direct = 1;          // hdb_topk_host: kernels write a pinned host record themselves (no D2H copy)
+    int64_t host_poll = 1;            // hdb_topk_host + single-launch pipeline + pinned record: poll the status words instead of the stream
     int64_t use_fused = 1;            // 1-4 dot / cosine queries on an fp16 matrix: the whole call in ONE kernel (hdb_mfma_fused.h)
     int64_t fused_timeout_us = 2000;  // bound of every in-kernel spin of that kernel
     int64_t finalize_threads = 1024;  // workgroup size of hdb_finalize_kernel (256 | 512 | 1024)
@@ -325,6 +328,7 @@ extern "C" int hdb_set_option(hdb_index* ix, const char* name, int64_t value) {
     else if (!strcmp(name, "mfma_variant")) { if (value == 16 || value == 32) ix->mfma_variant = value; }
     else if (!strcmp(name, "host_direct")) ix->host_direct = value;
     else if (!strcmp(name, "use_fused")) ix->use_fused = value;
+    else if (!strcmp(name, "host_poll")) ix->host_poll = value;
     else if (!strcmp(name, "fused_timeout_us")) ix->fused_timeout_us = std::max<int64_t>(1, value);
     else if (!strcmp(name, "bits_fused")) ix->bits_fused = value;
     else if (!strcmp(name, "profile")) { ix->profile = value; ix->ev_used = 0; }
@@ -735,10 +739,28 @@ extern "C" int hdb_topk_host(hdb_index* ix, const void* dev_Q, int32_t nq, int32
     int64_t* d_idx = reinterpret_cast<int64_t*>(rec);
     float* d_sc = reinterpret_cast<float*>(rec + (size_t)nq * k * 8);
     int32_t* d_st = reinterpret_cast<int32_t*>(rec + (size_t)nq * k * 12);
+    // Single-launch pipeline writing into a pinned record: its status words are stored last, behind a system-scope
+    // release, so the host can poll them instead of waiting for the kernel's completion signal (end-of-kernel drain,
+    // cache write-back, signal, wake-up: ~5 us).  The stream stays ordered: the next launch queues behind the kernel.
+    constexpr int32_t SENTINEL = 0x7FFFFFFF;
+    volatile int32_t* poll = reinterpret_cast<volatile int32_t*>(static_cast<char*>(host_record) + (size_t)nq * k * 12);
+    if (direct && ix->host_poll) for (int q = 0; q < nq; ++q) poll[q] = SENTINEL;
     int rc = topk_impl(ix, dev_Q, nq, k, metric, d_idx, d_sc, d_st, stream, false);
     if (rc) return rc;
     if (!direct) HIP_TRY(hipMemcpyAsync(host_record, rec, bytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    bool polled = false;
+    if (direct && ix->host_poll && ix->st_fused) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; ++spins) {
+            bool done = true;
+            for (int q = 0; q < nq; ++q) done &= poll[q] != SENTINEL;
+            if (done) { polled = true; break; }
+            if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;   // fall back to the signal
+            __builtin_ia32_pause();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    if (!polled) HIP_TRY(hipStreamSynchronize(st));
     const int32_t* h_st = reinterpret_cast<const int32_t*>(static_cast<const char*>(host_record) + (size_t)nq * k * 12);
     bool any_bad = false;
     for (int q = 0; q < nq; ++q) any_bad |= (h_st[q] & (HDB_Q_UNDERFLOW | HDB_Q_OVERFLOW)) != 0;

@@ -6,6 +6,10 @@
 #include "hdb_common.h"
 #include "../../include/hyperdb_hip.h"
 
+#ifndef HDB_FIN_STAMP
+#define HDB_FIN_STAMP(slot) do { } while (0)      // diagnostic builds of the fused kernel stamp the phases (tools/stamps_fused.py)
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // Finalize: sort the candidate list of one query (<= HDB_CAND_CAP packed entries) descending and
 // emit the first k.  1024 threads, 64 KiB of LDS.
@@ -27,7 +31,7 @@ __device__ __forceinline__ void hdb_bitonic_desc(unsigned long long* buf, int P)
 
 // Pre-selection for finalize/merge: keeps (in buf[0..ns)) a superset of the kk largest of buf[0..nc) that is
 // usually only a little larger than kk, so that the O(log^2) bitonic network runs on ~256 instead of ~4096
-// entries.  Monotone linear binning of the 32-bit score key into 2048 bins between the smallest and the
+// entries.  Monotone linear binning of the 32-bit score key into up to 2048 bins between the smallest and the
 // largest key present; everything in or above the bin holding the kk-th largest survives.  Exactness is
 // untouched: the survivors always contain the true top-kk, ties included.  Returns ns (>= min(kk, nc)).
 // hist: 2048 words of LDS; scratch: nc u64 of LDS (may alias nothing else).
@@ -46,8 +50,12 @@ static __device__ uint32_t hdb_preselect(unsigned long long* buf, uint32_t nc, u
     if (lane == 0) { atomicMin(&ctl[0], kmin); atomicMax(&ctl[1], kmax); }
     __syncthreads();
     kmin = ctl[0]; kmax = ctl[1];
-    const unsigned long long span = (unsigned long long)(kmax - kmin) + 1ull;
-    auto bin_of = [&](uint32_t k) { return (uint32_t)(((unsigned long long)(k - kmin) * NB) / span); };
+    // monotone binning by a shift (no 64-bit division: that alone was ~3 us of an 8 us pre-selection): the key range is
+    // cut into 1024..2047 equal bins
+    const uint32_t range = kmax - kmin;
+    const int bits = range ? 32 - __clz((int)range) : 0;
+    const int sh = bits > 11 ? bits - 11 : 0;
+    auto bin_of = [&](uint32_t k) { return (k - kmin) >> sh; };
     for (uint32_t i = tid; i < nc; i += nth) atomicAdd(&hist[bin_of((uint32_t)(buf[i] >> 32))], 1u);
     __syncthreads();
     // suffix scan from the top bin: thread t owns bins NB-1-2t, NB-2-2t (1024 threads) -- generic stride
@@ -94,10 +102,13 @@ __device__ __forceinline__ void hdb_finalize_body(unsigned long long* buf, const
     uint32_t* hist = reinterpret_cast<uint32_t*>(scratch + cap);
     uint32_t* ctl = hist + 2048;
     const uint32_t nc = total < cap ? total : cap;
+    HDB_FIN_STAMP(8);
     for (uint32_t i = threadIdx.x; i < nc; i += blockDim.x) buf[i] = cand[i];      // `cand` = this query's list
     __syncthreads();
+    HDB_FIN_STAMP(9);
     uint32_t ns = nc;
     if (nc > 512 && kk < nc / 2) ns = hdb_preselect(buf, nc, kk, hist, scratch, ctl);
+    HDB_FIN_STAMP(10);
     const uint32_t nout = nc < kk ? nc : kk;             // entries that exist
     if (ns <= 256) {
         // Few survivors (the usual case: ~kk plus one histogram bin): rank sort.  Packed entries are distinct, so the

@@ -30,7 +30,6 @@
 // not co-resident (another kernel holds CUs), never on an idle GPU: grid <= CU count, one workgroup fits per CU.
 #pragma once
 #include "hdb_mfma_kernel.h"
-#include "hdb_finalize.h"
 
 // Diagnostic build only (tools/stamps_fused.py; product: 0): wall-clock stamps (s_memrealtime, 100 MHz) of the phases
 // of every workgroup, stored in a buffer of their own that nothing reads: [wg][8] = start, prologue done, published,
@@ -40,11 +39,14 @@
 #define HDB_FUSED_STAMPS 0
 #endif
 #if HDB_FUSED_STAMPS
-static __device__ unsigned long long hdb_fused_stamps[8 * HDB_CLOCK_WGS_F];
-#define HDB_STAMP(slot) do { if (lane == 0 && stamp_wave) hdb_fused_stamps[8 * blockIdx.x + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+static __device__ unsigned long long hdb_fused_stamps[16 * HDB_CLOCK_WGS_F];
+#define HDB_STAMP(slot) do { if (lane == 0 && stamp_wave) hdb_fused_stamps[16 * blockIdx.x + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define HDB_FIN_STAMP(slot) do { if (threadIdx.x == 0) hdb_fused_stamps[16 * blockIdx.x + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define HDB_STAMP(slot) do { } while (0)
 #endif
+
+#include "hdb_finalize.h"
 
 #define HDB_FUSED_MAXQ 4            // queries per fused call
 #define HDB_FUSED_M 8               // sample order statistic (k <= 128)
@@ -588,7 +590,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     }
     HDB_STAMP(4);
 #if HDB_FUSED_STAMPS
-    if (tid == 0) hdb_fused_stamps[8 * blockIdx.x + 7] = (unsigned long long)(gp - nA);      // positions generated in phase B
+    if (tid == 0) hdb_fused_stamps[16 * blockIdx.x + 7] = (unsigned long long)(gp - nA);      // positions generated in phase B
 #endif
     flush();
 
@@ -613,13 +615,24 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
 #pragma unroll
         for (int q = 0; q < HDB_FUSED_MAXQ; ++q) if (q < nq && qpar[HDB_FUSED_MAXQ + q] != 0.f) qnan_bits |= 1u << q;
         __syncthreads();                             // everyone has its copy: fbuf may now cover ctl / qpar
+        // The status words are written LAST, behind a system-scope release: a host that polls them in a pinned record
+        // (hdb_topk_host) may read the results as soon as every word has left its sentinel value.
+        int32_t my_status = 0;
 #pragma unroll 1
         for (int q = 0; q < nq; ++q) {
-            const uint32_t tot = __hip_atomic_load(f.ctl + 2 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            hdb_finalize_body(fbuf, f.cand + (int64_t)q * f.cap, aborted ? 0u : tot, q, f.cap, f.k, f.kk, f.row_base, f.idx_out, f.score_out,
-                              f.status, (int)((qnan_bits >> q) & 1u), 0);
+            const uint32_t tot0 = __hip_atomic_load(f.ctl + 2 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t tot = aborted ? 0u : tot0;
+            hdb_finalize_body(fbuf, f.cand + (int64_t)q * f.cap, tot, q, f.cap, f.k, f.kk, f.row_base, f.idx_out, f.score_out,
+                              nullptr, 0, 0);
+            if (tid == q) {
+                const uint32_t nc = tot < f.cap ? tot : f.cap;
+                my_status = (tot > f.cap ? HDB_Q_OVERFLOW : 0) | (nc < f.kk ? HDB_Q_UNDERFLOW : 0) | (((qnan_bits >> q) & 1u) ? HDB_Q_NAN : 0);
+            }
             __syncthreads();
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // every thread's result stores are out
+        __syncthreads();
+        if (tid < nq && f.status) __hip_atomic_store(f.status + tid, my_status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         HDB_STAMP(6);
         if (tid < 2 + HDB_FUSED_MAXQ) __hip_atomic_store(f.ctl + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // clean for the next call
         if (tid == 32) __hip_atomic_store(f.ctl + 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -37,6 +37,6 @@ extern "C" int hdb_launch_mfma_fused(const ScanArgs* args, const FusedArgs* fa, 
 #if HDB_FUSED_STAMPS
 extern "C" int hdb_debug_read_fused_stamps(unsigned long long* host_out, int wgs) {
     if (wgs > HDB_CLOCK_WGS_F) wgs = HDB_CLOCK_WGS_F;
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(hdb_fused_stamps), (size_t)wgs * 8 * sizeof(unsigned long long));
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(hdb_fused_stamps), (size_t)wgs * 16 * sizeof(unsigned long long));
 }
 #endif

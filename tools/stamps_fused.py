@@ -36,9 +36,9 @@ def run():
         for i in range(40):
             t0 = time.perf_counter(); ix.topk_views(Q[i:i + 1], 100, mid); wall = (time.perf_counter() - t0) * 1e6
             if i < 10: continue
-            buf = (ctypes.c_uint64 * (8 * 256))()
+            buf = (ctypes.c_uint64 * (16 * 256))()
             lib.hdb_debug_read_fused_stamps(buf, 256)
-            a = np.frombuffer(buf, dtype=np.uint64).reshape(256, 8).astype(np.int64)
+            a = np.frombuffer(buf, dtype=np.uint64).reshape(256, 16).astype(np.int64)
             t_start = a[:, 0].min()
             rel = (a - t_start) / 100.0          # us
             last = int(np.argmax(a[:, 6]))
@@ -48,10 +48,10 @@ def run():
                       ' tiles generated min/med/max:', int(a[:, 7].min()), int(np.median(a[:, 7])), int(a[:, 7].max()),
                       ' tiles of the 5 last finishers:', a[order[-5:], 7].tolist(), ' of the 5 first:', a[order[:5], 7].tolist(), flush=True)
             rows.append([wall, rel[:, 0].max(), np.median(rel[:, 1]), np.median(rel[:, 2]), rel[:, 2].max(), np.median(rel[:, 3]), rel[:, 3].max(),
-                         np.median(rel[:, 4]), rel[:, 4].max(), rel[:, 5].max(), rel[last, 6]])
+                         np.median(rel[:, 4]), rel[:, 4].max(), rel[:, 5].max(), rel[last, 6], rel[last, 5], rel[last, 8], rel[last, 9], rel[last, 10]])
         r = np.median(np.array(rows), axis=0)
         names = ['host wall', 'last start', 'prologue done (med)', 'published (med)', 'published (max)', 'thr known (med)', 'thr known (max)',
-                 'loop done (med)', 'loop done (max)', 'ticket (max)', 'finalize done']
+                 'loop done (med)', 'loop done (max)', 'ticket (max)', 'finalize done', 'last WG: ticket', 'fin start', 'cands loaded', 'preselected']
         print(f"n={n}: " + ", ".join(f"{k} {v:.1f}" for k, v in zip(names, r)), flush=True)
         ix.close(); del V; torch.cuda.empty_cache()
 
