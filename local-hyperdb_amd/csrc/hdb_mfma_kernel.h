@@ -33,18 +33,28 @@ static __device__ unsigned long long hdb_clock_buf[4 * HDB_CLOCK_WGS];
 //   2  B waves issue the first fragment reads of tile i BEFORE their deferred epilogue of tile i-1
 //   4  s_setprio 1 for waves 4-7 (the arbitration losers of each SIMD), once, before the tile loop
 //   8  s_setprio 1 for waves 0-3 instead
-// Shipped: 0.  Measured on N=10M d=384 Q=256, two interleaved rounds per variant (profiles/r2_q256_experiments.json):
-// 0: 1.908 ms, 1: 1.935, 2: 1.938, 3: 1.938, 4: 1.890, 5: 1.918, 7: 1.916, 8: 1.906, 9: 1.930 -- the re-orderings cost
-// (the chip gives saved issue cycles back as clock), and the 1 % of variant 4 did not hold on a second MI355X, where the
-// same build ran 1.914 ms against 1.772 ms with the survivor append knocked out (without the priority: 1.801 vs 1.795).
+//  16  heavy pass: waves 4-7 stage the WHOLE tile (2*NG pieces each) right after the barrier, waves 0-3 stage nothing
+//  32  heavy pass: waves 0-3 stage the whole tile right after the barrier, waves 4-7 only the per-row aux values
+//  64  (with 16) only waves 6-7 stage: 4*NG pieces each
+// 128  (with 16) waves 4-7 stage the whole tile in EVERY pass, not only the heavy ones (up to 64 queries they do not multiply)
+// Shipped: 144 = 16 + 128: waves 4-7 stage every tile, right after the barrier; waves 0-3 never issue LDS-DMA.
+// Measured on N=10M d=384 Q=256 (kernel time, interleaved rounds per variant, profiles/r2_q256_experiments.json):
+//   first MI355X:  0: 1.908 ms, 1: 1.935, 2: 1.938, 3: 1.938, 4: 1.890, 5: 1.918, 7: 1.916, 8: 1.906, 9: 1.930
+//   second MI355X: 0: 1.906 ms, 16: 1.768, 32: 1.803, 20: 1.814, 80: 1.912
+// Re-ordering the work of a wave (1, 2) costs, static priorities (4, 8) move +-1 % and not reproducibly; what nets is
+// taking the LDS-DMA issue (~100-185 cycles of blocked issue per 1-KiB piece) away from half of the waves: with 16 the
+// two waves of a SIMD take turns on the matrix pipe -- A multiplies while B stages and filters, then B multiplies
+// while A filters -- instead of both stalling on their own staging.  128 extends it to the HBM-bound passes (up to 64
+// queries waves 4-7 do not multiply at all): d=384 Q=8 1.18 -> 1.12 ms, Q=64 1.30 -> 1.21, d=768 Q=64 euclidean + bias
+// 2.54 -> 2.41, d=128 Q=48 0.586 -> 0.489, N=1.25M Q=16 251 -> 214 us.
 #ifndef HDB_MFMA_EXP
-#define HDB_MFMA_EXP 0
+#define HDB_MFMA_EXP 144
 #endif
 
 #define HDB_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define HDB_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-template <int N> __device__ __forceinline__ void hdb_wait_vmcnt() {
+template <int N> __device__ __forceinline__ void hdb_wait_vmcnt() {      // s_waitcnt takes an immediate: one asm per value
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
     else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -60,7 +70,24 @@ template <int N> __device__ __forceinline__ void hdb_wait_vmcnt() {
     else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
     else if constexpr (N == 13) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
     else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-    else static_assert(N < 0, "add this vmcnt immediate");
+    else if constexpr (N == 15) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (N == 17) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+    else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    else if constexpr (N == 19) asm volatile("s_waitcnt vmcnt(19)" ::: "memory");
+    else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if constexpr (N == 21) asm volatile("s_waitcnt vmcnt(21)" ::: "memory");
+    else if constexpr (N == 22) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+    else if constexpr (N == 23) asm volatile("s_waitcnt vmcnt(23)" ::: "memory");
+    else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if constexpr (N == 25) asm volatile("s_waitcnt vmcnt(25)" ::: "memory");
+    else if constexpr (N == 26) asm volatile("s_waitcnt vmcnt(26)" ::: "memory");
+    else if constexpr (N == 27) asm volatile("s_waitcnt vmcnt(27)" ::: "memory");
+    else if constexpr (N == 28) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+    else if constexpr (N == 29) asm volatile("s_waitcnt vmcnt(29)" ::: "memory");
+    else if constexpr (N == 30) asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
+    else if constexpr (N == 31) asm volatile("s_waitcnt vmcnt(31)" ::: "memory");
+    else static_assert(N < 0, "vmcnt immediate out of range");
 }
 __device__ __forceinline__ void hdb_lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -226,6 +253,24 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
         for (int j = 0; j < NG; ++j) issue_piece(t, st, j);
         issue_aux(t, st);
     };
+    // EXP 16 / 32: one half of the waves stages all 8*NG pieces of the tile (piece p = (w & 3) + 4 j), offsets computed on the fly
+    auto issue_half = [&](int64_t t, int st) {
+        if ((HDB_MFMA_KNOCKOUT & 2) && t >= (int64_t)blockIdx.x + 3 * gstep) return;
+        const int64_t row0 = hdb_tile_index(t, tstride) * R;
+        const int64_t last = n_rows - 1 - row0;
+        char* sdst = smem + st * STAGE;
+        const char* tile_base = Vb + row0 * (int64_t)ROWB;
+        constexpr int HLW = (HDB_MFMA_EXP & 64) ? 2 : 4;      // staging waves
+#pragma unroll
+        for (int j = 0; j < (8 / HLW) * NG; ++j) {
+            const int pc = (w & (HLW - 1)) + HLW * j;
+            const int slot = pc * 64 + lane;
+            const int r = slot / CPR, cpos = slot - r * CPR;
+            const int rr = r <= (int)last ? r : (int)last;
+            const unsigned int off = (unsigned int)(rr * ROWB + (cpos ^ (r & 15)) * 16);
+            __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(tile_base + off), HDB_LDS_PTR(sdst + pc * 1024), 16, 0, 2);
+        }
+    };
 
     auto flush = [&]() {
         hdb_lds_barrier();
@@ -242,8 +287,16 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
     };
 
     int64_t t_cur = blockIdx.x;                      // global index of the tile being multiplied
-    if (my_tiles > 0) issue(t_cur, 0);
-    if (my_tiles > 1) issue(t_cur + gstep, 1);
+    constexpr bool HL = (HDB_MFMA_EXP & 48) != 0 && NG <= 6;
+    constexpr int HLN = ((HDB_MFMA_EXP & 64) ? 4 : 2) * NG;       // pieces per staging wave
+    const bool hl = HL && (heavy || (HDB_MFMA_EXP & 128));        // EXP 16 / 32: one half of the waves stages everything
+    const bool hl_loader = hl && (((HDB_MFMA_EXP & 16) != 0) == grpB) && (!(HDB_MFMA_EXP & 64) || w >= 6);
+    auto issue_any = [&](int64_t t, int st) {
+        if (hl) { if (hl_loader) issue_half(t, st); issue_aux(t, st); }
+        else issue(t, st);
+    };
+    if (my_tiles > 0) issue_any(t_cur, 0);
+    if (my_tiles > 1) issue_any(t_cur + gstep, 1);
 
     const unsigned int smem_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(smem);
     const unsigned int ctl_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(ctl);
@@ -333,7 +386,14 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
     int64_t row0_prev = 0;
     int st_cur = 0;
     for (int64_t i = 0; i < my_tiles; ++i, t_cur += gstep) {
+        constexpr int NAUX = NLOADB - NLOADA;
         if (i + 1 >= my_tiles) hdb_wait_vmcnt<0>();
+        else if (hl) {
+            if (hl_loader && grpB) hdb_wait_vmcnt<HLN + NAUX>();
+            else if (hl_loader) hdb_wait_vmcnt<HLN>();
+            else if (grpB) hdb_wait_vmcnt<NAUX>();
+            else hdb_wait_vmcnt<0>();
+        }
         else if (grpB) hdb_wait_vmcnt<NLOADB>();
         else hdb_wait_vmcnt<NLOADA>();
         // the LDS candidate list is checked for a flush every 16 tiles on large matrices (a few hits per tile,
@@ -353,7 +413,11 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
         constexpr bool SPREAD = (HDB_MFMA_EXP & 1) != 0 && KS >= 2 * NG;
         const bool spread = SPREAD && heavy && wave_active;       // pieces ride behind the MFMAs of the k-steps
         if (more && spread) issue_aux(t_cur + 2 * gstep, st_next2);
-        if (more && !spread && !(heavy && grpB)) issue(t_cur + 2 * gstep, st_next2);
+        if (more && hl) {
+            if (hl_loader) issue_half(t_cur + 2 * gstep, st_next2);
+            issue_aux(t_cur + 2 * gstep, st_next2);
+        }
+        if (more && !spread && !hl && !(heavy && grpB)) issue(t_cur + 2 * gstep, st_next2);
         if (chk && ctl[chk_slot]) flush();
 
         if (wave_active) {
@@ -482,7 +546,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
                 else row0_prev = row0;
             }
         }
-        if (more && heavy && grpB && !spread) issue(t_cur + 2 * gstep, st_next2);      // B's half of the staging, after its MFMA phase
+        if (more && heavy && grpB && !spread && !hl) issue(t_cur + 2 * gstep, st_next2);      // B's half of the staging, after its MFMA phase
         st_cur = st_cur == 2 ? 0 : st_cur + 1;
     }
 #if HDB_MFMA_CLOCK
