@@ -17,8 +17,9 @@
 //   * every wave multiplies the whole tile by its queries, one ds_read_b128 per QT MFMAs, issued 2-3 k-steps
 //     ahead from inline asm with counted lgkmcnt waits; accumulators never leave registers;
 //   * epilogue in registers: scale / bias / threshold compare behind a group-max prefilter; survivors go
-//     to a small LDS list that is flushed to the per-query candidate lists with global atomics every few
-//     hundred tiles.  The N x Q score matrix is never written (10 GB at N=10M, Q=256).
+//     to a wave-private segment of a small LDS list (slot = running count + ballot rank, no atomic), which each wave
+//     empties into the per-query candidate lists with global atomics when it fills.  The N x Q score matrix is never
+//     written (10 GB at N=10M, Q=256).
 // Synchronisation: one raw s_barrier per tile; tile t+2 is in flight while tile t is multiplied (counted
 // s_waitcnt vmcnt, never 0 in the steady state).
 // Algorithmic bytes per row: d*2 (V read exactly once per pass); FLOPs: 2*Q*d per row.
