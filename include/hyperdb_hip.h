@@ -130,7 +130,7 @@ int hdb_scores(hdb_index* ix, const void* dev_q, int metric, float* dev_out, voi
  * dev_score [nq][k] float32, sorted by (score descending, index ascending).
  * dev_status [nq] int32 receives hdb_query_status bits; queries with a non-zero status must be
  * re-run with hdb_topk_exact (the threshold estimate from the row sample failed for them).
- * On fp16 matrices (d in {128,256,384,512,640,768,1024,1536}; dot, cosine, euclidean, pearson) the
+ * On fp16 matrices (d any multiple of 128 up to 1536; dot, cosine, euclidean, pearson) the
  * scores come from the matrix cores with fp16 copies of the queries (scaled per query by a power of two, so any
  * float32 magnitude is safe) and float32 accumulation: nothing is lost when the query has the matrix's dtype, a
  * float32 query is rounded to 11 significant bits per element (score error ~1e-4 relative, inside the 1e-3

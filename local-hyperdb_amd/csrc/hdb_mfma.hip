@@ -70,27 +70,21 @@ __global__ __launch_bounds__(256) void hdb_rescore_euclid_kernel(unsigned long l
     }
 }
 
-// Geometry table: rows per LDS stage (stage = R * row bytes <= 48 KiB, three stages + lists <= 160 KiB).
-// fp16: 16x16x32 MFMAs, 128 queries per pass (d=384 with more than 128 queries: two query tiles per wave, 256 per pass).
+// Geometry: rows per LDS stage = the largest of 64 / 32 / 16 whose stage (R * row bytes) fits 48 KiB (three stages + lists
+// <= 160 KiB).  Rows are multiples of 256 bytes (the XOR swizzle works on 16 chunks of 16 bytes), so every d that is a
+// multiple of 128 (fp16) / 64 (fp32) works; the upper limits are the query fragments a wave holds in registers: d/8
+// (fp16) or d/4 (fp32) registers for 16 queries, 192 at most.
+// fp16: 16x16x32 MFMAs, 128 queries per pass (d <= 640 with more than 128 queries: two query tiles per wave, 256 per pass).
 // fp32: 16x16x4 MFMAs, 128 queries per pass; the matrix pipe (157 TFLOP/s) binds from ~16 queries on, so the VALU scan
 // keeps the calls of up to 4 queries (one pass at HBM speed) and this path takes the batches.
 extern "C" int hdb_mfma_tile_rows(int dtype, int d) {
-    if (dtype == HDB_F16) {
-        switch (d) {
-            case 128: case 256: case 384: return 64;
-            case 512: case 640: case 768: return 32;
-            case 1024: case 1536: return 16;
-            default: return 0;
-        }
-    }
-    if (dtype == HDB_F32) {
-        switch (d) {
-            case 128: return 64;
-            case 256: case 384: return 32;
-            case 512: case 768: return 16;
-            default: return 0;
-        }
-    }
+    const int elem = dtype == HDB_F16 ? 2 : dtype == HDB_F32 ? 4 : 0;
+    if (!elem || d <= 0) return 0;
+    const int row_bytes = d * elem;
+    if (row_bytes % 256 != 0 || row_bytes > 3072) return 0;          // d <= 1536 (fp16) / 768 (fp32)
+    if (dtype == HDB_F32 && d != 128 && d != 256 && d != 384 && d != 512 && d != 768) return 0;     // instantiated fp32 widths
+    for (int r = 64; r >= 16; r >>= 1)
+        if (r * row_bytes <= 48 * 1024) return r;
     return 0;
 }
 
@@ -108,6 +102,8 @@ extern "C" int hdb_launch_mfma_scan_f16_qt2(const ScanArgs* args, int mode, int 
                                             const float* qsq, const float* qscl, int blocks, void* stream);
 extern "C" int hdb_launch_mfma_scan_f32(const ScanArgs* args, int mode, int nq_launch, const void* q, const float* sqnorm,
                                         const float* qsq, int blocks, void* stream);
+extern "C" int hdb_launch_mfma_scan_f16_wide(const ScanArgs* args, int mode, int nq_launch, const void* q16, const float* sqnorm,
+                                             const float* qsq, const float* qscl, int blocks, void* stream);
 
 // a.ntiles / a.tile_stride are in units of hdb_mfma_tile_rows(dtype, d) rows here.  q: the query fragments' source --
 // scaled fp16 copies (+ qscl) for fp16 matrices, the float32 queries themselves (qscl = nullptr) for fp32 ones.
@@ -140,7 +136,7 @@ extern "C" int hdb_launch_mfma_scan(const ScanArgs* args, int dtype, int mode, i
         case 768: return launch_mode<_Float16, 16, 1, 768, 32>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
         case 1024: return launch_mode<_Float16, 16, 1, 1024, 16>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
         case 1536: return launch_mode<_Float16, 16, 1, 1536, 16>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
-        default: return (int)hipErrorNotSupported;
+        default: return hdb_launch_mfma_scan_f16_wide(args, mode, nq_launch, q16, sqnorm, qsq, qscl, blocks, stream);     // 896, 1152, 1280, 1408
     }
 }
 

@@ -28,29 +28,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 static __device__ unsigned long long hdb_clock_buf[4 * HDB_CLOCK_WGS];
 #endif
 
-// Experiment switches for the 256-query ("heavy") pass, A/B-timed by tools/exp_q256.py (bit mask):
-//   1  the staging of tile i+2 is spread over the MFMA phase (A waves: one 1-KiB piece behind each of the first NG
-//      k-steps, B waves: behind the last NG) instead of issued as one block of NG pieces
-//   2  B waves issue the first fragment reads of tile i BEFORE their deferred epilogue of tile i-1
-//   4  s_setprio 1 for waves 4-7 (the arbitration losers of each SIMD), once, before the tile loop
-//   8  s_setprio 1 for waves 0-3 instead
-//  16  heavy pass: waves 4-7 stage the WHOLE tile (2*NG pieces each) right after the barrier, waves 0-3 stage nothing
-//  32  heavy pass: waves 0-3 stage the whole tile right after the barrier, waves 4-7 only the per-row aux values
-//  64  (with 16) only waves 6-7 stage: 4*NG pieces each
-// 128  (with 16) waves 4-7 stage the whole tile in EVERY pass, not only the heavy ones (up to 64 queries they do not multiply)
-// Shipped: 144 = 16 + 128: waves 4-7 stage every tile, right after the barrier; waves 0-3 never issue LDS-DMA.
-// Measured on N=10M d=384 Q=256 (kernel time, interleaved rounds per variant, profiles/r2_q256_experiments.json):
-//   first MI355X:  0: 1.908 ms, 1: 1.935, 2: 1.938, 3: 1.938, 4: 1.890, 5: 1.918, 7: 1.916, 8: 1.906, 9: 1.930
-//   second MI355X: 0: 1.906 ms, 16: 1.768, 32: 1.803, 20: 1.814, 80: 1.912
-// Re-ordering the work of a wave (1, 2) costs, static priorities (4, 8) move +-1 % and not reproducibly; what nets is
-// taking the LDS-DMA issue (~100-185 cycles of blocked issue per 1-KiB piece) away from half of the waves: with 16 the
-// two waves of a SIMD take turns on the matrix pipe -- A multiplies while B stages and filters, then B multiplies
-// while A filters -- instead of both stalling on their own staging.  128 extends it to the HBM-bound passes (up to 64
-// queries waves 4-7 do not multiply at all): d=384 Q=8 1.18 -> 1.12 ms, Q=64 1.30 -> 1.21, d=768 Q=64 euclidean + bias
-// 2.54 -> 2.41, d=128 Q=48 0.586 -> 0.489, N=1.25M Q=16 251 -> 214 us.
-#ifndef HDB_MFMA_EXP
-#define HDB_MFMA_EXP 144
-#endif
+// Staging roles (measured, profiles/r2_q256_experiments.json, N=10M d=384 Q=256, interleaved rounds per variant on one
+// MI355X each): with every wave staging its eighth of a tile (round 1) the two waves of a SIMD both stalled on their own
+// LDS-DMA issue (~100-185 blocked cycles per 1-KiB piece): 1.906 ms.  Variants: pieces spread between the MFMAs 1.935,
+// fragment reads before the deferred epilogue 1.938, s_setprio 1 for waves 4-7 1.890 on one box and worse on another,
+// for waves 0-3 1.906, waves 0-3 staging everything 1.803, only waves 6-7 staging 1.912, and the one that is shipped:
+// WAVES 4-7 STAGE EVERY TILE (PPL pieces each) right after the barrier, waves 0-3 never issue LDS-DMA: 1.768 ms.
+// The two waves of a SIMD then take turns on the matrix pipe -- A multiplies while B stages and filters, then B
+// multiplies while A filters.  In the HBM-bound passes (up to 64 queries waves 4-7 do not multiply at all) the same
+// split gives d=384 Q=8 1.18 -> 1.12 ms, Q=64 1.30 -> 1.21, d=768 Q=64 euclidean + bias 2.54 -> 2.41, d=128 Q=48
+// 0.586 -> 0.489, N=1.25M Q=16 251 -> 214 us.
 
 #define HDB_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define HDB_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -142,12 +129,11 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
     // so that few queries still spread their MFMAs over all four SIMDs (fp32 MFMAs bind long before HBM does)
     constexpr int RT = R / MF / RS;             // MFMA row tiles per stage and wave
     constexpr int STAGE = R * ROWB;             // bytes of V per stage
-    constexpr int NG = R * CPR / 64 / 8;        // LDS-DMA instructions per wave per tile
+    constexpr int PPL = R * CPR / 64 / 4;       // LDS-DMA pieces (1 KiB) per staging wave and tile: waves 4-7 stage
     constexpr bool AUX0 = METRIC != 0;
-    constexpr int NLOADA = NG;
-    constexpr int NLOADB = NG + (AUX0 ? 1 : 0) + (HAS_BIAS ? 1 : 0);     // B waves also stage the per-row aux values
+    constexpr int NAUX = (AUX0 ? 1 : 0) + (HAS_BIAS ? 1 : 0);            // per-row aux values, staged by every B wave
     constexpr int QPW = MF * QT;                // queries per wave (QT query tiles share every A fragment)
-    static_assert(R % (MF * RS) == 0 && 8 % RS == 0 && R <= 64 && (R * CPR) % 512 == 0 && ROWB % 256 == 0 && KS % NG == 0, "tile geometry");
+    static_assert(R % (MF * RS) == 0 && 8 % RS == 0 && R <= 64 && (R * CPR) % 256 == 0 && ROWB % 256 == 0 && PPL + NAUX <= 31, "tile geometry");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* auxbuf = reinterpret_cast<float*>(smem + 3 * STAGE);                    // [3 stages][2][64]
@@ -197,20 +183,9 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
     // Waves 0-3 ("A") and 4-7 ("B") are the two waves of each SIMD.  B runs its threshold epilogue one tile
     // late so that the two waves of a SIMD do not reach MFMA phase, epilogue and barrier in lock-step.
     const bool grpB = w >= 4;
-    // "heavy": all eight waves multiply (more than 4*MF queries in this pass), the matrix pipe is the bottleneck.
-    // Then A stages its half of tile i+2 right after the barrier while B already multiplies, and B stages its
-    // half after its MFMA phase while A finishes -- the two waves of a SIMD never issue LDS-DMA (~90 cycles of
-    // blocked issue per 1 KiB piece) at the same time.  Otherwise (HBM-bound) everyone stages right away.
-    const bool heavy = (nq_end - (a.q0 + (int)blockIdx.y * ((8 / RS) * QPW))) > (4 / RS) * QPW;
+    // B also stages every tile (see the note on staging roles at the top of this file); with up to 4*MF*QT queries in a
+    // pass the B waves have no queries and do nothing else.
 
-    // ---- staging geometry (per lane, fixed for the whole kernel) -----------------------------------
-    int g_off[NG];
-#pragma unroll
-    for (int j = 0; j < NG; ++j) {
-        const int slot = (w + 8 * j) * 64 + lane;
-        const int r = slot / CPR, cpos = slot - r * CPR;
-        g_off[j] = r * ROWB + (cpos ^ (r & 15)) * 16;   // source byte for this LDS slot (XOR swizzle of the chunk)
-    }
     // loop-invariant scalars, read once (keeps kernel-argument loads out of the tile loop)
     const char* const Vb = reinterpret_cast<const char*>(a.V);
     const int64_t n_rows = a.n;
@@ -219,26 +194,9 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
     const int64_t gstep = gridDim.x;
     const int64_t my_tiles = (ntiles > blockIdx.x) ? (ntiles - blockIdx.x + gstep - 1) / gstep : 0;
 
-    // Stage tile number t (global tile index) into ring slot st: NG LDS-DMA pieces of 1 KiB per wave,
-    // non-temporal (V is read once per pass by exactly one CU: +2-3 % on the HBM-bound shapes), plus the
-    // per-row aux values (B waves only).  Only the last tile of the matrix can be ragged.
-    // piece j (0..NG-1) of tile t -> ring slot st
-    auto issue_piece = [&](int64_t t, int st, int j) {
-        if ((HDB_MFMA_KNOCKOUT & 2) && t >= (int64_t)blockIdx.x + 3 * gstep) return;
-        const int64_t row0 = hdb_tile_index(t, tstride) * R;
-        const int64_t last = n_rows - 1 - row0;          // >= 0
-        char* sdst = smem + st * STAGE;
-        const char* tile_base = Vb + row0 * (int64_t)ROWB;             // wave-uniform
-        if (last >= R - 1) {
-            __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(tile_base + (unsigned int)g_off[j]),
-                                             HDB_LDS_PTR(sdst + (w + 8 * j) * 1024), 16, 0, 2);
-        } else {                                                        // clamp rows past the end to the last row
-            const int r = g_off[j] / ROWB;
-            const int rr = r <= (int)last ? r : (int)last;
-            const unsigned int off = (unsigned int)(g_off[j] + (rr - r) * ROWB);
-            __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(tile_base + off), HDB_LDS_PTR(sdst + (w + 8 * j) * 1024), 16, 0, 2);
-        }
-    };
+    // Stage tile number t (global tile index) into ring slot st: waves 4-7 issue PPL LDS-DMA pieces of 1 KiB each
+    // (piece p = (w & 3) + 4 j; its source offset carries the XOR swizzle of the chunk), non-temporal (V is read once per
+    // pass by exactly one CU), plus the per-row aux values.  Only the last tile of the matrix can be ragged.
     auto issue_aux = [&](int64_t t, int st) {
         if ((HDB_MFMA_KNOCKOUT & 2) && t >= (int64_t)blockIdx.x + 3 * gstep) return;
         if ((AUX0 || HAS_BIAS) && grpB) {
@@ -249,22 +207,15 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
             if (HAS_BIAS) __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(a.bias + row0 + rr), HDB_LDS_PTR(auxbuf + (st * 2 + 1) * 64), 4, 0, 0);
         }
     };
-    auto issue = [&](int64_t t, int st) {
-#pragma unroll
-        for (int j = 0; j < NG; ++j) issue_piece(t, st, j);
-        issue_aux(t, st);
-    };
-    // EXP 16 / 32: one half of the waves stages all 8*NG pieces of the tile (piece p = (w & 3) + 4 j), offsets computed on the fly
-    auto issue_half = [&](int64_t t, int st) {
+    auto issue_rows = [&](int64_t t, int st) {
         if ((HDB_MFMA_KNOCKOUT & 2) && t >= (int64_t)blockIdx.x + 3 * gstep) return;
         const int64_t row0 = hdb_tile_index(t, tstride) * R;
         const int64_t last = n_rows - 1 - row0;
         char* sdst = smem + st * STAGE;
         const char* tile_base = Vb + row0 * (int64_t)ROWB;
-        constexpr int HLW = (HDB_MFMA_EXP & 64) ? 2 : 4;      // staging waves
 #pragma unroll
-        for (int j = 0; j < (8 / HLW) * NG; ++j) {
-            const int pc = (w & (HLW - 1)) + HLW * j;
+        for (int j = 0; j < PPL; ++j) {
+            const int pc = (w & 3) + 4 * j;
             const int slot = pc * 64 + lane;
             const int r = slot / CPR, cpos = slot - r * CPR;
             const int rr = r <= (int)last ? r : (int)last;
@@ -294,16 +245,11 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
     };
 
     int64_t t_cur = blockIdx.x;                      // global index of the tile being multiplied
-    constexpr bool HL = (HDB_MFMA_EXP & 48) != 0 && NG <= 6;
-    constexpr int HLN = ((HDB_MFMA_EXP & 64) ? 4 : 2) * NG;       // pieces per staging wave
-    const bool hl = HL && (heavy || (HDB_MFMA_EXP & 128));        // EXP 16 / 32: one half of the waves stages everything
-    const bool hl_loader = hl && (((HDB_MFMA_EXP & 16) != 0) == grpB) && (!(HDB_MFMA_EXP & 64) || w >= 6);
-    auto issue_any = [&](int64_t t, int st) {
-        if (hl) { if (hl_loader) issue_half(t, st); issue_aux(t, st); }
-        else issue(t, st);
+    auto issue = [&](int64_t t, int st) {
+        if (grpB) { issue_rows(t, st); issue_aux(t, st); }
     };
-    if (my_tiles > 0) issue_any(t_cur, 0);
-    if (my_tiles > 1) issue_any(t_cur + gstep, 1);
+    if (my_tiles > 0) issue(t_cur, 0);
+    if (my_tiles > 1) issue(t_cur + gstep, 1);
 
     const unsigned int smem_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(smem);
     // per-lane LDS read address: row rl of a row tile; chunk (CPS*s + h) ^ rx of k-step s is at byte
@@ -382,8 +328,6 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
         for (int qt = 0; qt < QT; ++qt) filter1(tv[qt], row0, thr_cmp[qt], qinv_l[qt], ql[qt]);
     };
 
-    if ((HDB_MFMA_EXP & 4) && grpB && heavy) __builtin_amdgcn_s_setprio(1);     // only where the matrix pipe is the bottleneck
-    if ((HDB_MFMA_EXP & 8) && !grpB && heavy) __builtin_amdgcn_s_setprio(1);
 #if HDB_MFMA_CLOCK
     const unsigned long long clk_c0 = __builtin_amdgcn_s_memtime(), clk_r0 = __builtin_amdgcn_s_memrealtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0) alone: keeps the loop's counted LDS waits as written
@@ -392,33 +336,17 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
     int64_t row0_prev = 0;
     int st_cur = 0;
     for (int64_t i = 0; i < my_tiles; ++i, t_cur += gstep) {
-        constexpr int NAUX = NLOADB - NLOADA;
         if (i + 1 >= my_tiles) hdb_wait_vmcnt<0>();
-        else if (hl) {
-            if (hl_loader && grpB) hdb_wait_vmcnt<HLN + NAUX>();
-            else if (hl_loader) hdb_wait_vmcnt<HLN>();
-            else if (grpB) hdb_wait_vmcnt<NAUX>();
-            else hdb_wait_vmcnt<0>();
-        }
-        else if (grpB) hdb_wait_vmcnt<NLOADB>();
-        else hdb_wait_vmcnt<NLOADA>();
+        else if (grpB) hdb_wait_vmcnt<PPL + NAUX>();         // all but the newest tile's pieces are in
         if (!(HDB_MFMA_KNOCKOUT & 4)) hdb_lds_barrier();     // tile i is in LDS; everyone is done with tile i-1
-        // Stage the whole next-but-one tile right after the barrier, into the buffer tile i-1 used (measured:
-        // 5.4-5.7 TB/s on the HBM-bound shapes vs 4.7-5.0 with the pieces spread between the MFMAs).
+        // Stage the whole next-but-one tile right after the barrier, into the buffer tile i-1 used.
         const bool more = i + 2 < my_tiles;
         const int st_next2 = st_cur == 0 ? 2 : st_cur - 1;
-        constexpr bool SPREAD = (HDB_MFMA_EXP & 1) != 0 && KS >= 2 * NG;
-        const bool spread = SPREAD && heavy && wave_active;       // pieces ride behind the MFMAs of the k-steps
-        if (more && spread) issue_aux(t_cur + 2 * gstep, st_next2);
-        if (more && hl) {
-            if (hl_loader) issue_half(t_cur + 2 * gstep, st_next2);
-            issue_aux(t_cur + 2 * gstep, st_next2);
-        }
-        if (more && !spread && !hl && !(heavy && grpB)) issue(t_cur + 2 * gstep, st_next2);
+        if (more) issue(t_cur + 2 * gstep, st_next2);
 
         if (wave_active) {
             const int64_t row0 = hdb_tile_index(t_cur, tstride) * R;
-            if (!(HDB_MFMA_EXP & 2) && MODE == 1 && grpB && i > 0) filter(acc, row0_prev);        // deferred epilogue of tile i-1
+            if (MODE == 1 && grpB && i > 0) filter(acc, row0_prev);        // deferred epilogue of tile i-1
             // A fragments: LDS reads issued two k-steps ahead of the MFMAs that consume them.  The reads
             // and their counted waits are inline asm so that hipcc cannot sink a read next to its use
             // (it otherwise emits read, lgkmcnt(0), MFMA per step and exposes the LDS latency every step).
@@ -451,8 +379,6 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
             };
 #pragma unroll
             for (int s = 0; s < PF && s < KS; ++s) fetch(s, abuf[s % (PF + 1)]);
-            // EXP 2: the fragment reads of tile i are in flight while B finishes tile i-1 in the VALU
-            if ((HDB_MFMA_EXP & 2) && MODE == 1 && grpB && i > 0) filter(acc, row0_prev);
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
@@ -468,12 +394,6 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
                 for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) acc[qt][rt] = Shape::mma(abuf[s % (PF + 1)][rt], Bq[qt][s], acc[qt][rt]);
-                if constexpr (SPREAD) {
-                    if (more && spread) {
-                        if (!grpB && s < NG) issue_piece(t_cur + 2 * gstep, st_next2, s);
-                        if (grpB && s >= KS - NG) issue_piece(t_cur + 2 * gstep, st_next2, s - (KS - NG));
-                    }
-                }
             }
 
             // ---- epilogue, first half: turn the dot products into the values that are stored (MODE 0) or
@@ -542,7 +462,6 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
                 else row0_prev = row0;
             }
         }
-        if (more && heavy && grpB && !spread && !hl) issue(t_cur + 2 * gstep, st_next2);      // B's half of the staging, after its MFMA phase
         st_cur = st_cur == 2 ? 0 : st_cur + 1;
     }
 #if HDB_MFMA_CLOCK

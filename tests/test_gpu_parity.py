@@ -584,7 +584,11 @@ def test_mfma_with_recency_bias(orc):
                                               (1024, 128, "euclidean_metric", True), (1536, 32, "dot_product", False),
                                               (1536, 70, "cosine_similarity", True), (256, 200, "cosine_similarity", False),
                                               (512, 256, "euclidean_metric", True), (640, 129, "dot_product", False),
-                                              (128, 256, "dot_product", True)])
+                                              (128, 256, "dot_product", True),
+                                              # every multiple of 128 up to 1536 rides the matrix cores (16-row stages, 7-11 pieces per staging wave)
+                                              (896, 40, "cosine_similarity", False), (1152, 33, "dot_product", True),
+                                              (1280, 64, "euclidean_metric", False), (1408, 17, "cosine_similarity", True),
+                                              (896, 128, "euclidean_metric", True)])
 def test_mfma_shapes_and_euclidean(orc, d, nq, metric, bias):
     """Config-5 shaped case (d=768, Q=64, euclidean + time decay) and the other MFMA geometries."""
     import torch
@@ -733,7 +737,7 @@ def test_fuzz_sampled_threshold_equals_exact_selection(seed):
     import torch
     from hyperdb._native import GpuIndex, METRIC_IDS
     rng = np.random.default_rng(seed)
-    mfma_d = [128, 256, 384, 512, 640, 768, 1024, 1536]
+    mfma_d = [128, 256, 384, 512, 640, 768, 896, 1024, 1152, 1280, 1408, 1536]
     for case in range(10):
         use16 = rng.random() < 0.7
         d = int(rng.choice(mfma_d)) if use16 else int(rng.choice([24, 100, 384, 200]))
