@@ -50,7 +50,7 @@ int hdb_launch_mfma_scan(const ScanArgs* args, int dtype, int mode, int nq_launc
                          const float* qsq, const float* qscl, int max_blocks, int variant, void* stream);
 int hdb_mfma_fused_supported(int dtype, int d, int metric, int nq, uint32_t kk);
 size_t hdb_mfma_fused_ctl_bytes(void);
-int hdb_launch_mfma_fused(const ScanArgs* args, const FusedArgs* fa, int max_blocks, void* stream);
+int hdb_launch_mfma_fused(const ScanArgs* args, int dtype, const FusedArgs* fa, int max_blocks, void* stream);
 int hdb_launch_q_to_f16(const float* Q, int nq, int d, void* q16, float* qscl, void* stream);
 int hdb_sort_temp_bytes(int64_t n, size_t* bytes);
 int hdb_launch_full_sort(const float* scores, int64_t n, int64_t k, int64_t row_base, uint32_t* work, void* temp, size_t temp_bytes,
@@ -518,7 +518,11 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     const int64_t min_q = ix->dtype == HDB_F32 ? std::max<int64_t>(ix->mfma_min_q, 5) : ix->mfma_min_q;
     const bool mfma = ix->use_mfma && !is_ham && !small && nq >= min_q &&
                       hdb_mfma_supported(ix->dtype, ix->d, is_pearson ? (int)HDB_COSINE : metric);
-    const int tile_rows = mfma ? hdb_mfma_tile_rows(ix->dtype, ix->d) : 16;
+    // 1-4 dot / cosine queries, k <= 128: one launch does everything (hdb_mfma_fused.h; fp16 on the matrix cores,
+    // float32 in the VALU from the same staged tiles)
+    const bool fused_shape = ix->use_fused && !exact && !small && k <= HDB_MAX_K && dev_status != nullptr && !is_ham && !is_pearson &&
+                             hdb_mfma_fused_supported(ix->dtype, ix->d, metric, nq, kk) && (ix->dtype == HDB_F32 || mfma);
+    const int tile_rows = (mfma || fused_shape) ? hdb_mfma_tile_rows(ix->dtype, ix->d) : 16;
 
     // ---- plan the chunking --------------------------------------------------------------------
     int64_t s_tiles = 0, s_stride = 1; uint32_t m = 0;
@@ -553,9 +557,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     unsigned long long* cand = b.take<unsigned long long>((size_t)cq_max * HDB_CAND_CAP);
     float* sbuf = b.take<float>((size_t)cq_max * (exact && !small ? ld_n : ld_s));
 
-    // 1-4 dot / cosine queries, k <= 128, fp16 matrix: one launch does everything (no prep kernel either)
-    const bool fused = mfma && ix->use_fused && !exact && !small && !full_sort && m == 8 && dev_status != nullptr &&
-                       hdb_mfma_fused_supported(ix->dtype, ix->d, metric, nq, kk);
+    const bool fused = fused_shape && !full_sort && m == 8;           // (no prep kernel either)
     // the MFMA scan multiplies with fp16 queries: written by the same kernel (pearson converts its centred copy later)
     const bool f16_queries = mfma && ix->dtype == HDB_F16;          // fp32 matrices multiply with the float32 queries as they are
     const bool q16_in_prep = f16_queries && !is_pearson && !full_sort;
@@ -607,7 +609,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     // the MFMA scan has no mask input: excluded rows get a bias of -inf instead (never appended, like the VALU scan)
     const float* bias_eff = ix->bias;
     const uint8_t* mask_eff = ix->mask;
-    if (mfma && ix->mask) {
+    if ((mfma || fused) && ix->mask) {
         if (n > ix->mbias_rows) {
             if (ix->mbias) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(ix->mbias)); ix->mbias = nullptr; }
             const int64_t rows = n + n / 4 + 64;
@@ -638,9 +640,9 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
         fa.ctl = reinterpret_cast<uint32_t*>(ix->fctl);
         fa.cand = cand; fa.cap = HDB_CAND_CAP; fa.k = (uint32_t)k; fa.kk = kk; fa.row_base = ix->row_base;
         fa.idx_out = dev_idx; fa.score_out = dev_score; fa.status = dev_status; fa.thr_out = thr;
-        ix->st_sample_rows = s_rows; ix->st_sample_m = m; ix->st_chunks = 1; ix->st_path = 1; ix->st_mfma = 1; ix->st_fused = 1;
+        ix->st_sample_rows = s_rows; ix->st_sample_m = m; ix->st_chunks = 1; ix->st_path = 1; ix->st_mfma = ix->dtype == HDB_F16 ? 1 : 0; ix->st_fused = 1;
         prof_begin(ix, st);
-        LAUNCH_TRY(hdb_launch_mfma_fused(&a, &fa, (int)ix->max_blocks, st));
+        LAUNCH_TRY(hdb_launch_mfma_fused(&a, ix->dtype, &fa, (int)ix->max_blocks, st));
         prof_end(ix, st);
         return HDB_OK;
     }

@@ -74,13 +74,24 @@ __device__ __forceinline__ float hdb_lds_ld32(unsigned int addr) {
 typedef __attribute__((address_space(1))) unsigned long long hdb_gu64;
 typedef __attribute__((address_space(1))) unsigned int hdb_gu32;
 
-template <int D, int R, int METRIC, bool HAS_BIAS>
+// E = _Float16: wave 0 multiplies on the matrix cores (fp16 copies of the queries as B fragments).
+// E = float (the reference's default fp_precision, BASELINE config 2): wave 0 computes the float32 dot products in the
+// VALU straight from the staged tile (16 lanes x 16 B per row and pass, four rows per 16-lane group, the DPP ownership
+// butterfly of hdb_scan.hip): for 1-4 queries that is ~200 v_fma per 32-row tile, far below what an fp32 MFMA spends on
+// its 16 query columns, and exact float32 arithmetic (1e-5 contract).
+template <typename E, int VQ, int D, int R, int METRIC, bool HAS_BIAS>
 __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedArgs f, const float* __restrict__ aux0g) {
+    constexpr bool VALU = sizeof(E) == 4;
     using Shape = MfmaShape<16, _Float16>;
     using Vec = typename Shape::Vec;
     using Acc = typename Shape::Acc;
     constexpr int MF = 16;
-    constexpr int ROWB = D * 2;
+    constexpr int ROWB = D * (int)sizeof(E);
+    constexpr int NJ = ROWB / 256;              // VALU: 16-byte chunks per lane and row (16 lanes cover a row)
+    constexpr int NP = R / 16;                  // VALU: 16-row passes per tile ...
+    constexpr int NPW = NP / 2;                 // ... per computing wave (two of them)
+    // VQ (VALU flavour only): queries per call, 1 or 2 -- their chunks live in registers (VQ x D/16 of them), and a
+    // single query must not pay for a second one
     constexpr int CPR = ROWB / 16;
     constexpr int CPS = Shape::CPS;
     constexpr int KS = CPR / CPS;
@@ -93,6 +104,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     constexpr int NLOADB = NGL + (AUX0 ? 1 : 0) + (HAS_BIAS ? 1 : 0);
     constexpr int M = HDB_FUSED_M;
     static_assert(R % MF == 0 && R <= 64 && (R * CPR) % 512 == 0 && ROWB % 256 == 0, "tile geometry");
+    static_assert(!VALU || (NJ * VQ <= 12 && NP % 2 == 0), "float32 flavour: query chunks in registers, two computing waves");
     static_assert(METRIC == 0 || METRIC == 1, "dot / cosine");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -102,7 +114,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     unsigned int* ctl = reinterpret_cast<unsigned int*>(cbq + HDB_MFMA_CB);       // [0] count, [1..2] flush flags, [3] last-workgroup flag
     float* tsc = reinterpret_cast<float*>(ctl + 16);                               // [2][MAXQ][64] scores of the latest sample tiles
     float* qpar = tsc + 2 * HDB_FUSED_MAXQ * 64;                                   // [MAXQ] multiplier, [MAXQ] NaN flag, [MAXQ] threshold
-    _Float16* qlds = reinterpret_cast<_Float16*>(smem + 2 * STAGE);               // prologue scratch: [nq][D] fp16 (ring slot 2, not yet in use)
+    char* qlds = smem + 2 * STAGE;                                                // prologue scratch: [nq][D] queries in E (ring slot 2, not yet in use)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -112,8 +124,11 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     const bool loader = w >= 4;                     // waves 4-7 stage the tiles
     const bool grpB = w >= 6;                       // ... 6-7 also the per-row aux values
     const int lw = w & 3;
-    const bool mfma_wave = w == 0;                  // nq <= 16: one wave multiplies, the kernel is a streaming kernel
-    const bool selector = (w == 1 || w == 2) && 2 * (w - 1) < nq;   // wave 1: queries 0-1, wave 2: queries 2-3
+    // fp16: wave 0 multiplies (nq <= 16: the kernel is a streaming kernel); wave 1: selector of queries 0-1, wave 2: of 2-3.
+    // float32: waves 0 and 2 compute (even / odd 16-row passes of a tile), wave 1 is the selector of both queries.
+    const bool mfma_wave = w == 0 || (VALU && w == 2);
+    const int pp0 = VALU ? (w >> 1) : 0;            // first pass of this computing wave
+    const bool selector = (w == 1 || (w == 2 && !VALU)) && 2 * (w - 1) < nq;
     const bool requester = w == 3;
     const int64_t G = gridDim.x;
     const int64_t b = blockIdx.x;
@@ -230,12 +245,16 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
         for (int u = 0; u < QPL; ++u) { ss += qreg[u] * qreg[u]; amax = fmaxf(amax, fabsf(qreg[u])); }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { ss += __shfl_xor(ss, o, 64); amax = fmaxf(amax, __shfl_xor(amax, o, 64)); }
-        const float scale = hdb_q16_scale(amax);
+        const float scale = VALU ? 1.f : hdb_q16_scale(amax);
 #pragma unroll
         for (int u = 0; u < QPL; ++u) {
             const int e = lane + 64 * u;
-            const _Float16 hv = (_Float16)(qreg[u] * scale);
-            if (e < D) hdb_lds_st16(qlds_addr + (unsigned int)(w * D + e) * 2u, (unsigned int)__builtin_bit_cast(unsigned short, hv));
+            if constexpr (VALU) {
+                if (e < D) hdb_lds_st32(qlds_addr + (unsigned int)(w * D + e) * 4u, qreg[u]);
+            } else {
+                const _Float16 hv = (_Float16)(qreg[u] * scale);
+                if (e < D) hdb_lds_st16(qlds_addr + (unsigned int)(w * D + e) * 2u, (unsigned int)__builtin_bit_cast(unsigned short, hv));
+            }
         }
         if (lane == 0) {
             const float qinv = (ss == 0.f) ? 1.0f : 1.0f / sqrtf(ss);
@@ -248,23 +267,43 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
 
     // ---- wave 0: B fragments and per-query constants ---------------------------------------------
     const bool q_ok = rl < nq;
-    Vec Bq[KS];
+    Vec Bq[VALU ? 1 : KS];
     float qinv_l = 1.f;
+    // VALU flavour: lane (group g = lane >> 4, l16 = lane & 15) holds chunks l16 + 16 j of every query, and the per-query
+    // multipliers / thresholds as wave-uniform values
+    const int l16 = lane & 15, g4 = lane >> 4;
+    f32x4 qv[VALU ? VQ : 1][VALU ? NJ : 1];
+    float qmul[VQ], thr_q[VQ];
+#pragma unroll
+    for (int q = 0; q < VQ; ++q) { qmul[q] = 1.f; thr_q[q] = INFINITY; }
     if (mfma_wave) {
-        const unsigned int src = qlds_addr + (unsigned int)((q_ok ? rl : 0) * D) * 2u + (unsigned int)h * 16u;
+        if constexpr (VALU) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            Vec v;
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(src), "i"(CPS * 16 * s));
-            Bq[s] = v;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int q = 0; q < VQ; ++q) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            asm volatile("" : "+v"(Bq[s]));                  // values are final only behind the wait above
-            if (!q_ok) Bq[s] = Vec{0, 0, 0, 0, 0, 0, 0, 0};
+                for (int j = 0; j < NJ; ++j) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (q < nq) asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(qlds_addr + (unsigned int)(q * D) * 4u + (unsigned int)(l16 + 16 * j) * 16u) : "memory");
+                    qv[q][j] = v;
+                }
+                if (q < nq) qmul[q] = hdb_lds_ld32(qpar_addr + (unsigned int)q * 4u);
+            }
+        } else {
+            const unsigned int src = qlds_addr + (unsigned int)((q_ok ? rl : 0) * D) * 2u + (unsigned int)h * 16u;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                Vec v;
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(src), "i"(CPS * 16 * s));
+                Bq[s] = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                asm volatile("" : "+v"(Bq[s]));                  // values are final only behind the wait above
+                if (!q_ok) Bq[s] = Vec{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+            if (q_ok) qinv_l = hdb_lds_ld32(qpar_addr + (unsigned int)rl * 4u);
         }
-        if (q_ok) qinv_l = hdb_lds_ld32(qpar_addr + (unsigned int)rl * 4u);
     }
 
     const unsigned int smem_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(smem);
@@ -341,6 +380,34 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                                 if (gpos < f.cap) f.cand[(int64_t)rl * f.cap + gpos] = hdb_pack(sc, (uint32_t)(rowg + j));
                             }
                         }
+                    }
+                }
+            }
+        }
+    };
+
+    // VALU flavour: the comparable values of a tile, one row per owning lane ((l16 & 3) == 0) and pass
+    float pend[VALU ? NPW : 1][VQ];
+    auto filter_valu = [&](const float (&tv)[VALU ? NPW : 1][VQ], int64_t row0) {
+        const int u_own = hdb_owned_row(l16);
+#pragma unroll
+        for (int k2 = 0; k2 < (VALU ? NPW : 1); ++k2) {
+            const int pp = 2 * k2 + pp0;
+            const int64_t row = row0 + 16 * pp + 4 * g4 + u_own;
+#pragma unroll
+            for (int q = 0; q < VQ; ++q) {
+                const float x = tv[k2][q];
+                if (q < nq && (l16 & 3) == 0 && x >= thr_q[q] && row < n_rows && !(HAS_BIAS && x == -INFINITY)) {
+                    const float sc = hdb_canon(HAS_BIAS ? x : x * qmul[q]);
+                    unsigned int pos;
+                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pos) : "v"(ctl_addr), "v"(1u) : "memory");
+                    const unsigned long long ent = hdb_pack(sc, (uint32_t)row);
+                    if (pos < HDB_MFMA_CB) {
+                        asm volatile("ds_write_b64 %0, %1\n\tds_write_b16 %2, %3"
+                                     :: "v"(cb_addr + pos * 8u), "v"(ent), "v"(cbq_addr + pos * 2u), "v"((unsigned int)q) : "memory");
+                    } else {
+                        const unsigned int gpos = atomicAdd(&f.ctl[2 + q], 1u);
+                        if (gpos < f.cap) f.cand[(int64_t)q * f.cap + gpos] = ent;
                     }
                 }
             }
@@ -500,6 +567,91 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
         }
 
         // ---- wave 0: multiply tile i; epilogue of a sample tile at once, of a filter tile one round later ----
+        if constexpr (VALU) {
+        if (mfma_wave) {
+            if (have_prev) {                         // deferred epilogue of tile i-1 (phase B)
+                if (thr_reads > 0) {                 // written by the selectors before this round's barrier; later sweeps raise it
+#pragma unroll
+                    for (int q = 0; q < VQ; ++q)
+                        if (q < nq) thr_q[q] = hdb_lds_ld32(qpar_addr + (unsigned int)(2 * HDB_FUSED_MAXQ + q) * 4u);
+                    --thr_reads;
+                }
+                filter_valu(pend, row0_prev);
+                have_prev = false;
+            }
+            if (tile) {
+                const int64_t row0 = rA;
+                const char* tbase = smem + st_cur * STAGE;
+                const float* ax0 = auxbuf + (st_cur * 2 + 0) * 64;
+                const float* ax1 = auxbuf + (st_cur * 2 + 1) * 64;
+                const int u_own = hdb_owned_row(l16);
+#pragma unroll
+                for (int k2 = 0; k2 < NPW; ++k2) {
+                    const int pp = 2 * k2 + pp0;
+                    // rows 16 pp + 4 g4 + u (u = 0..3); chunk c of row r sits at ((c ^ (r & 15)) << 4) of its row image
+                    float accv[4][VQ];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int q = 0; q < VQ; ++q) accv[u][q] = 0.f;
+                    constexpr int JB = NJ % 3 == 0 ? 3 : (NJ % 2 == 0 ? 2 : 1);       // chunks in flight per row and step (registers)
+#pragma unroll
+                    for (int j0 = 0; j0 < NJ; j0 += JB) {
+                        __builtin_amdgcn_sched_barrier(0);     // keep hipcc from hoisting the next step's 12 reads over this one (spills)
+                        f32x4 raw[JB][4];
+#pragma unroll
+                        for (int j = 0; j < JB; ++j)
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int r = 16 * pp + 4 * g4 + u;
+                                raw[j][u] = *reinterpret_cast<const f32x4*>(tbase + r * ROWB + (((l16 + 16 * (j0 + j)) ^ (r & 15)) << 4));
+                            }
+#pragma unroll
+                        for (int j = 0; j < JB; ++j)
+#pragma unroll
+                            for (int q = 0; q < VQ; ++q)
+#pragma unroll
+                                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) accv[u][q] = fmaf(raw[j][u][e], qv[q][j0 + j][e], accv[u][q]);
+                    }
+                    const int rloc = 16 * pp + 4 * g4 + u_own;             // the row this lane owns after the butterfly
+                    const float a0 = AUX0 ? ax0[rloc] : 1.f;
+                    const float b0 = HAS_BIAS ? ax1[rloc] : 0.f;
+#pragma unroll
+                    for (int q = 0; q < VQ; ++q) {
+                        const float dot = hdb_rows4_sum(accv[0][q], accv[1][q], accv[2][q], accv[3][q], l16);
+                        const float rawv = METRIC == 1 ? dot * a0 : dot;
+                        // rounding steps of hdb_emit (hdb_scan.hip): product rounded, THEN the bias added -- the empty asm keeps
+                        // hipcc from contracting the two into one fma, so both pipelines return bit-identical scores
+                        float scaled = rawv * qmul[q];
+                        asm volatile("" : "+v"(scaled));
+                        pend[k2][q] = HAS_BIAS ? scaled + b0 : rawv;
+                    }
+                }
+                if (i < nA) {                        // sample tile: scores to the selectors (read after the next barrier)
+                    if ((l16 & 3) == 0) {
+#pragma unroll
+                        for (int q = 0; q < VQ; ++q) {
+                            if (q < nq) {
+                                const unsigned int dst = tsc_addr + (unsigned int)(((int)(i & 1) * HDB_FUSED_MAXQ + q) * 64) * 4u;
+#pragma unroll
+                                for (int k2 = 0; k2 < NPW; ++k2) hdb_lds_st32(dst + (unsigned int)(16 * (2 * k2 + pp0) + 4 * g4 + u_own) * 4u, pend[k2][q]);
+                            }
+                        }
+                    }
+                    if (R < 64 && w == 0 && lane < 64 - R) {   // shorter tiles: the rest of the 64-entry row is -inf
+#pragma unroll
+                        for (int q = 0; q < VQ; ++q)
+                            if (q < nq) hdb_lds_st32(tsc_addr + (unsigned int)((((int)(i & 1) * HDB_FUSED_MAXQ + q) * 64) + R + lane) * 4u, -INFINITY);
+                    }
+                } else {
+                    row0_prev = row0;
+                    have_prev = true;
+                }
+            }
+        }
+        } else {
         if (mfma_wave) {
             if (have_prev) {                         // deferred epilogue of tile i-1 (phase B)
                 if (thr_reads > 0) {                 // written by the selectors before this round's barrier; later sweeps raise it
@@ -584,6 +736,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                 }
             }
         }
+        }
         st_cur = st_cur == 2 ? 0 : st_cur + 1;
         rA = rB; vA = vB; rB = rC; vB = vC;
         if (!tile) break;
@@ -645,10 +798,10 @@ static size_t fused_lds_bytes(int stage_bytes) {
     return scan > fin ? scan : fin;
 }
 
-template <int D, int R, int METRIC, bool HAS_BIAS>
+template <typename E, int VQ, int D, int R, int METRIC, bool HAS_BIAS>
 static int launch_fused_one(const ScanArgs& a, const FusedArgs& f, const float* aux0, int blocks, hipStream_t st) {
-    auto kern = hdb_mfma_fused_kernel<D, R, METRIC, HAS_BIAS>;
-    const size_t lds = fused_lds_bytes(R * D * 2);
+    auto kern = hdb_mfma_fused_kernel<E, VQ, D, R, METRIC, HAS_BIAS>;
+    const size_t lds = fused_lds_bytes(R * D * (int)sizeof(E));
     static unsigned long long attr_done = 0;
     hipError_t e = hdb_lds_attr_once(reinterpret_cast<const void*>(kern), (int)lds, &attr_done);
     if (e != hipSuccess) return (int)e;
@@ -656,10 +809,10 @@ static int launch_fused_one(const ScanArgs& a, const FusedArgs& f, const float* 
     return (int)hipGetLastError();
 }
 
-template <int D, int R>
+template <typename E, int VQ, int D, int R>
 static int launch_fused(const ScanArgs& a, const FusedArgs& f, int blocks, hipStream_t st) {
     const bool bias = a.bias != nullptr;
-    if (a.metric == HDB_DOT) return bias ? launch_fused_one<D, R, 0, true>(a, f, nullptr, blocks, st) : launch_fused_one<D, R, 0, false>(a, f, nullptr, blocks, st);
-    if (a.metric == HDB_COSINE) return bias ? launch_fused_one<D, R, 1, true>(a, f, a.inv_norm, blocks, st) : launch_fused_one<D, R, 1, false>(a, f, a.inv_norm, blocks, st);
+    if (a.metric == HDB_DOT) return bias ? launch_fused_one<E, VQ, D, R, 0, true>(a, f, nullptr, blocks, st) : launch_fused_one<E, VQ, D, R, 0, false>(a, f, nullptr, blocks, st);
+    if (a.metric == HDB_COSINE) return bias ? launch_fused_one<E, VQ, D, R, 1, true>(a, f, a.inv_norm, blocks, st) : launch_fused_one<E, VQ, D, R, 1, false>(a, f, a.inv_norm, blocks, st);
     return (int)hipErrorNotSupported;
 }

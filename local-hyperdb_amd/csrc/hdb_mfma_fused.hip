@@ -6,14 +6,15 @@ extern "C" int hdb_mfma_tile_rows(int dtype, int d);
 
 extern "C" int hdb_mfma_fused_supported(int dtype, int d, int metric, int nq, uint32_t kk) {
     // d <= 768: beyond that the query fragments (d/8 registers) leave no room for the selectors' state without spilling
-    return dtype == HDB_F16 && hdb_mfma_tile_rows(dtype, d) > 0 && d <= 768 && (metric == HDB_DOT || metric == HDB_COSINE) &&
-           nq >= 1 && nq <= HDB_FUSED_MAXQ && kk <= 128;
+    const bool shape = (dtype == HDB_F16 && hdb_mfma_tile_rows(dtype, d) > 0 && d <= 768) ||
+                       (dtype == HDB_F32 && (d == 128 || d == 256 || d == 384));      // float32: VALU flavour, up to 2 queries (48 query registers at d = 384)
+    return shape && (metric == HDB_DOT || metric == HDB_COSINE) && nq >= 1 && nq <= (dtype == HDB_F32 ? 2 : HDB_FUSED_MAXQ) && kk <= 128;
 }
 
 // bytes of the persistent control block: 64 words of counters + the granules
 extern "C" size_t hdb_mfma_fused_ctl_bytes(void) { return 256 + (size_t)HDB_FUSED_MAX_WG * HDB_FUSED_GRAN_PER_WG * 8; }
 
-extern "C" int hdb_launch_mfma_fused(const ScanArgs* args, const FusedArgs* fa, int max_blocks, void* stream) {
+extern "C" int hdb_launch_mfma_fused(const ScanArgs* args, int dtype, const FusedArgs* fa, int max_blocks, void* stream) {
     const ScanArgs& a = *args;
     FusedArgs f = *fa;
     hipStream_t st = (hipStream_t)stream;
@@ -23,13 +24,21 @@ extern "C" int hdb_launch_mfma_fused(const ScanArgs* args, const FusedArgs* fa, 
     if (blocks > HDB_FUSED_MAX_WG) blocks = HDB_FUSED_MAX_WG;
     if (blocks < 1) blocks = 1;
     f.gran = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(f.ctl) + 256);
+    if (dtype == HDB_F32) {
+        switch (a.d) {
+            case 128: return f.nq == 1 ? launch_fused<float, 1, 128, 64>(a, f, blocks, st) : launch_fused<float, 2, 128, 64>(a, f, blocks, st);
+            case 256: return f.nq == 1 ? launch_fused<float, 1, 256, 32>(a, f, blocks, st) : launch_fused<float, 2, 256, 32>(a, f, blocks, st);
+            case 384: return f.nq == 1 ? launch_fused<float, 1, 384, 32>(a, f, blocks, st) : launch_fused<float, 2, 384, 32>(a, f, blocks, st);
+            default: return (int)hipErrorNotSupported;
+        }
+    }
     switch (a.d) {
-        case 128: return launch_fused<128, 64>(a, f, blocks, st);
-        case 256: return launch_fused<256, 64>(a, f, blocks, st);
-        case 384: return launch_fused<384, 64>(a, f, blocks, st);
-        case 512: return launch_fused<512, 32>(a, f, blocks, st);
-        case 640: return launch_fused<640, 32>(a, f, blocks, st);
-        case 768: return launch_fused<768, 32>(a, f, blocks, st);
+        case 128: return launch_fused<_Float16, 2, 128, 64>(a, f, blocks, st);
+        case 256: return launch_fused<_Float16, 2, 256, 64>(a, f, blocks, st);
+        case 384: return launch_fused<_Float16, 2, 384, 64>(a, f, blocks, st);
+        case 512: return launch_fused<_Float16, 2, 512, 32>(a, f, blocks, st);
+        case 640: return launch_fused<_Float16, 2, 640, 32>(a, f, blocks, st);
+        case 768: return launch_fused<_Float16, 2, 768, 32>(a, f, blocks, st);
         default: return (int)hipErrorNotSupported;
     }
 }

@@ -1284,3 +1284,43 @@ def test_single_launch_pipeline_failure_paths(ranking, orc):
         assert int(st[0].item()) == 0 and torch.equal(fi, ei) and torch.equal(fs, es)
     finally:
         ix.close()
+
+
+@pytest.mark.parametrize("n,d", [(8193, 384), (70_001, 128), (250_000, 256), (400_003, 384)])
+def test_single_launch_pipeline_float32(orc, n, d):
+    """float32 matrices (the reference's default fp_precision, BASELINE config 2): 1-2 dot / cosine queries run as one launch
+    whose float32 dot products are computed in the VALU from the staged tiles -- bit-identical to the five-kernel VALU
+    pipeline and the exact selection (same accumulation order, same rounding steps), and within 1e-5 of the oracle."""
+    import torch
+    from hyperdb._native import GpuIndex, METRIC_IDS
+    rng = np.random.default_rng(n * 3 + d)
+    V = rng.standard_normal((n, d)).astype(np.float32)
+    V[n - 1] = V[11]
+    Q = rng.standard_normal((3, d)).astype(np.float32)
+    Q[1] = V[n // 2] + 0.01 * rng.standard_normal(d).astype(np.float32)
+    ix = GpuIndex(V)
+    try:
+        bias = torch.rand(n, generator=torch.Generator().manual_seed(5)).float().cuda() * 0.2
+        mask = (torch.rand(n, generator=torch.Generator().manual_seed(6)) < 0.4).to(torch.uint8).cuda()
+        for metric in ("cosine_similarity", "dot_product"):
+            mid = METRIC_IDS[metric]
+            for setup in ("plain", "bias", "mask+bias"):
+                ix.set_bias(bias if "bias" in setup else None)
+                ix.set_row_mask(mask if "mask" in setup else None)
+                for nq, k in ((1, 100), (2, 7), (1, 128)):
+                    ix.set_option("use_fused", 1)
+                    fi, fs, fst = ix.topk_device(Q[:nq], k, mid)
+                    assert ix.stat("fused") == 1 and ix.stat("mfma") == 0 and int(fst.abs().sum().item()) == 0, (metric, setup, nq, k)
+                    ix.set_option("use_fused", 0)
+                    ui, us, _ = ix.topk_device(Q[:nq], k, mid)
+                    assert ix.stat("fused") == 0
+                    ei, es, _ = ix.topk_device(Q[:nq], k, mid, exact=True)
+                    assert torch.equal(fi, ei) and torch.equal(fs, es) and torch.equal(fi, ui) and torch.equal(fs, us), (metric, setup, nq, k)
+            ix.set_bias(None); ix.set_row_mask(None); ix.set_option("use_fused", 1)
+            idx, sc = ix.topk(Q[:2], 100, mid)
+            assert ix.stat("fused") == 1
+            for qi in range(2):
+                orc.check_topk(idx[qi], sc[qi], V, Q[qi], metric, 100, tol=1e-5)
+        ix.topk_device(Q[:3], 10, METRIC_IDS["dot_product"]); assert ix.stat("fused") == 0      # three float32 queries: five-kernel pipeline
+    finally:
+        ix.close()

@@ -27,10 +27,10 @@ def run():
     dev = torch.device('cuda', 0)
     lib = _native.lib()
     lib.hdb_debug_read_fused_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
-    for n in (1_250_000, 10_000_000):
-        V, lo, hi = bench.make_shard(n, 384, torch.float16, 0, 1, dev)
+    for (n, dt) in ((1_250_000, torch.float16), (10_000_000, torch.float16), (1_000_000, torch.float32)):
+        V, lo, hi = bench.make_shard(n, 384, dt, 0, 1, dev)
         ix = GpuIndex(V)
-        Q = bench.make_queries(64, 384, torch.float16, dev).to(torch.float32)
+        Q = bench.make_queries(64, 384, dt, dev).to(torch.float32)
         mid = METRIC_IDS['cosine_similarity']
         rows = []
         for i in range(40):
@@ -52,7 +52,7 @@ def run():
         r = np.median(np.array(rows), axis=0)
         names = ['host wall', 'last start', 'prologue done (med)', 'published (med)', 'published (max)', 'thr known (med)', 'thr known (max)',
                  'loop done (med)', 'loop done (max)', 'ticket (max)', 'finalize done', 'last WG: ticket', 'fin start', 'cands loaded', 'preselected']
-        print(f"n={n}: " + ", ".join(f"{k} {v:.1f}" for k, v in zip(names, r)), flush=True)
+        print(f"n={n} {dt}: " + ", ".join(f"{k} {v:.1f}" for k, v in zip(names, r)), flush=True)
         ix.close(); del V; torch.cuda.empty_cache()
 
 if __name__ == '__main__':
