@@ -242,7 +242,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     if (w < nq) {
         float ss = 0.f, amax = 0.f;
 #pragma unroll
-        for (int u = 0; u < QPL; ++u) { ss += qreg[u] * qreg[u]; amax = fmaxf(amax, fabsf(qreg[u])); }
+        for (int u = 0; u < QPL; ++u) { ss = fmaf(qreg[u], qreg[u], ss); amax = fmaxf(amax, fabsf(qreg[u])); }   // as hdb_qprep_kernel
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { ss += __shfl_xor(ss, o, 64); amax = fmaxf(amax, __shfl_xor(amax, o, 64)); }
         const float scale = VALU ? 1.f : hdb_q16_scale(amax);

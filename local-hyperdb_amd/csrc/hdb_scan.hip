@@ -275,7 +275,7 @@ __global__ __launch_bounds__(64) void hdb_qprep_kernel(const Acc* Q, int nq, int
     float amax = 0.f;
     for (int e = threadIdx.x; e < d; e += 64) {
         const Acc x = Q[(int64_t)q * d + e];
-        s += x * x;
+        s = fma(x, x, s);                       // explicit fma: the fused kernel's prologue must reproduce this sum bit for bit
         amax = fmaxf(amax, fabsf((float)x));
     }
     if (q16) {

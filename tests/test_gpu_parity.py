@@ -1216,6 +1216,7 @@ def test_single_launch_pipeline_equals_multi_kernel_and_oracle(orc, n, d):
     V[n - 1] = V[7]                                        # duplicate rows across the matrix ends: tie -> lower row first
     Q = rng.standard_normal((4, d)).astype(np.float16).astype(np.float32)
     Q[1] = V[n // 3].astype(np.float32)
+    Q[2] = rng.standard_normal(d).astype(np.float32) * 37.5          # a genuinely float32 query: norm sums must round alike in both pipelines
     ix = GpuIndex(V)
     try:
         bias = torch.rand(n, generator=torch.Generator().manual_seed(3)).float().cuda() * 0.2
