@@ -31,7 +31,7 @@ int hdb_launch_hamming(const ScanArgs* args, int mode, int nq_launch, const uint
 int hdb_launch_hist(const float* scores, int64_t n, int64_t ld, int nq, uint32_t* hist, int pass, uint32_t k, void* stream);
 int hdb_launch_thr(const uint32_t* hist, int nq, int npass, uint32_t m, uint32_t sample_n, float* thr, uint32_t* cnt, void* stream);
 int hdb_launch_fill_thr(float* thr, uint32_t* cnt, int nq, float v, void* stream);
-int hdb_launch_sample_thr(const float* scores, int64_t n, int64_t ld, int nq, uint32_t m, float* thr, uint32_t* cnt, void* stream);
+int hdb_launch_sample_thr(const float* scores, int64_t n, int64_t ld, int nq, uint32_t m, float* thr, uint32_t* cnt, uint32_t* tile_ctr, void* stream);
 int hdb_launch_collect(const float* scores, int64_t n, int64_t ld, int nq, const uint32_t* hist, int npass, uint32_t k, uint32_t* cnt,
                        unsigned long long* cand, uint32_t cap, uint32_t* tie_info, void* stream);
 int hdb_launch_finalize(const unsigned long long* cand, const uint32_t* cnt, uint32_t cap, int nq, uint32_t k, uint32_t kk,
@@ -121,6 +121,7 @@ struct hdb_index {
     int64_t exact_bytes = (int64_t)1 << 30;
     int64_t bits_fused = 1;           // hamming / jaccard: try the sampled-threshold path first (exact path when it fails)
     int64_t host_direct = 1;          // hdb_topk_host: kernels write a pinned host record themselves (no D2H copy)
+    int64_t dyn_tiles = 1;            // MFMA filter pass of up to 64 queries: hand tiles out from a counter (0: static split)
     int64_t host_poll = 1;            // hdb_topk_host + single-launch pipeline + pinned record: poll the status words instead of the stream
     int64_t use_fused = 1;            // 1-4 dot / cosine queries on an fp16 matrix: the whole call in ONE kernel (hdb_mfma_fused.h)
     int64_t fused_timeout_us = 2000;  // bound of every in-kernel spin of that kernel
@@ -329,6 +330,7 @@ extern "C" int hdb_set_option(hdb_index* ix, const char* name, int64_t value) {
     else if (!strcmp(name, "host_direct")) ix->host_direct = value;
     else if (!strcmp(name, "use_fused")) ix->use_fused = value;
     else if (!strcmp(name, "host_poll")) ix->host_poll = value;
+    else if (!strcmp(name, "dyn_tiles")) ix->dyn_tiles = value;
     else if (!strcmp(name, "fused_timeout_us")) ix->fused_timeout_us = std::max<int64_t>(1, value);
     else if (!strcmp(name, "bits_fused")) ix->bits_fused = value;
     else if (!strcmp(name, "profile")) { ix->profile = value; ix->ev_used = 0; }
@@ -539,7 +541,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     need += align_up((size_t)nq * W * 4, 256);                               // qbits
     need += align_up((size_t)nq * ix->d * 2, 256);                           // fp16 queries (MFMA)
     need += align_up((size_t)nq * ix->d * 8, 256);                           // centred queries (pearson)
-    need += 2 * align_up((size_t)cq_max * 4, 256);                           // thr, cnt
+    need += 2 * align_up((size_t)cq_max * 4, 256) + 256;                     // thr, cnt, tile counter
     need += align_up((size_t)cq_max * 4 * HDB_RADIX_BINS * 4, 256);          // hist
     need += align_up((size_t)cq_max * 16, 256);                              // tie_info
     need += align_up((size_t)cq_max * HDB_CAND_CAP * 8, 256);                // cand
@@ -552,6 +554,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     void* q16 = b.take<uint16_t>((size_t)nq * ix->d);
     void* qc = b.take<double>((size_t)nq * ix->d);
     float* thr = b.take<float>(cq_max); uint32_t* cnt = b.take<uint32_t>(cq_max);
+    uint32_t* tile_ctr = b.take<uint32_t>(64);
     uint32_t* hist = b.take<uint32_t>((size_t)cq_max * 4 * HDB_RADIX_BINS);
     uint32_t* tie_info = b.take<uint32_t>((size_t)cq_max * 4);
     unsigned long long* cand = b.take<unsigned long long>((size_t)cq_max * HDB_CAND_CAP);
@@ -672,7 +675,8 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
             rc = run_scan(ix, s, 0, cq, qb, mfma, st); if (rc) return rc;
             // 2) m-th largest sample score per query
             if (m <= 16) {
-                LAUNCH_TRY(hdb_launch_sample_thr(sbuf, s_rows, ld_s, cq, m, thr, cnt, st));
+                LAUNCH_TRY(hdb_launch_sample_thr(sbuf, s_rows, ld_s, cq, m, thr, cnt, tile_ctr, st));
+                if (mfma && ix->dyn_tiles) a.tile_ctr = tile_ctr;       // zeroed just now: dynamic tile hand-out in the pass
             } else {
                 HIP_TRY(hipMemsetAsync(hist, 0, (size_t)cq * 4 * HDB_RADIX_BINS * 4, st));
                 for (int p = 0; p < 4; ++p) LAUNCH_TRY(hdb_launch_hist(sbuf, s_rows, ld_s, cq, hist, p, m, st));

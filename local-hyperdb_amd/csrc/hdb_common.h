@@ -40,6 +40,7 @@ struct ScanArgs {
     uint32_t cap;
     int32_t nq;             // total number of queries behind Q
     int32_t raw;            // 1: keep NaN scores as NaN (per-metric functions); 0: NaN -> -inf (ranking)
+    uint32_t* tile_ctr;     // MFMA filter pass: zeroed counter that hands out tiles dynamically (nullptr: static split)
 };
 
 // Extra arguments of the single-launch top-k (hdb_mfma_fused.h): sample plan, exchange block, outputs.

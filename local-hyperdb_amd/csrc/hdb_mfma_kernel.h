@@ -192,24 +192,19 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
     const int64_t ntiles = a.ntiles;
     const int64_t tstride = a.tile_stride;                      // 1 = dense pass, > 1 = strided row sample
     const int64_t gstep = gridDim.x;
-    const int64_t my_tiles = (ntiles > blockIdx.x) ? (ntiles - blockIdx.x + gstep - 1) / gstep : 0;
 
     // Stage tile number t (global tile index) into ring slot st: waves 4-7 issue PPL LDS-DMA pieces of 1 KiB each
     // (piece p = (w & 3) + 4 j; its source offset carries the XOR swizzle of the chunk), non-temporal (V is read once per
     // pass by exactly one CU), plus the per-row aux values.  Only the last tile of the matrix can be ragged.
-    auto issue_aux = [&](int64_t t, int st) {
-        if ((HDB_MFMA_KNOCKOUT & 2) && t >= (int64_t)blockIdx.x + 3 * gstep) return;
+    auto issue_aux = [&](int64_t row0, int st) {
         if ((AUX0 || HAS_BIAS) && grpB) {
-            const int64_t row0 = hdb_tile_index(t, tstride) * R;
             const int64_t last = n_rows - 1 - row0;
             const int64_t rr = lane <= last ? lane : last;
             if (AUX0) __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(aux0g + row0 + rr), HDB_LDS_PTR(auxbuf + (st * 2 + 0) * 64), 4, 0, 0);
             if (HAS_BIAS) __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(a.bias + row0 + rr), HDB_LDS_PTR(auxbuf + (st * 2 + 1) * 64), 4, 0, 0);
         }
     };
-    auto issue_rows = [&](int64_t t, int st) {
-        if ((HDB_MFMA_KNOCKOUT & 2) && t >= (int64_t)blockIdx.x + 3 * gstep) return;
-        const int64_t row0 = hdb_tile_index(t, tstride) * R;
+    auto issue_rows = [&](int64_t row0, int st) {
         const int64_t last = n_rows - 1 - row0;
         char* sdst = smem + st * STAGE;
         const char* tile_base = Vb + row0 * (int64_t)ROWB;
@@ -244,12 +239,68 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
         wcnt = 0;
     };
 
-    int64_t t_cur = blockIdx.x;                      // global index of the tile being multiplied
-    auto issue = [&](int64_t t, int st) {
-        if (grpB) { issue_rows(t, st); issue_aux(t, st); }
+    // ---- tile sequence ---------------------------------------------------------------------------------
+    // Static: workgroup b takes tiles b, b+G, ...  Dynamic (filter pass of up to 4*MF*QT queries, one query block, a zeroed
+    // counter in a.tile_ctr, >= 32 tiles per workgroup): the first chunk of CH tiles is fixed, later chunks come from the
+    // counter (CH tiles per request, CH/2 near the end) -- CUs differ in streaming speed (hdb_mfma_fused.h) and the slowest
+    // workgroup of a static split finishes 3-5 % of the pass after the median one.  Wave 3 owns the counter: it is the last
+    // of the multiplying waves to get queries, so up to 3*MF*QT queries it has nothing else to do, and beyond that it
+    // multiplies for a quarter of a round; waves 4-7, which stage, never wait for the counter.  The request goes out LOOK
+    // rounds (~3 us of streaming, the counter answers in ~1.5 us) before the chunk is needed; the answer is handed over
+    // through LDS.
+    const bool heavy = (nq_end - (a.q0 + (int)blockIdx.y * ((8 / RS) * QPW))) > (4 / RS) * QPW;    // all eight waves multiply
+    const int64_t G = gstep, bidx = blockIdx.x;
+    // Measured (10 M rows, 8-64 queries, static -> dynamic): d=768 2.29 -> 2.18 ms, d=1536 (2.5 M rows) 1.149 -> 1.109,
+    // d=512 (5 M) 0.775 -> 0.764, d=384 1.120 -> 1.106; but d=128 401 -> 438 us, d=256 (5 M) 394 -> 404, d=384 at 2.5 M rows
+    // 298 -> 303: short rows (rounds shorter than the hand-over) and short passes (the end of a pass is decided in chunks)
+    // lose, so dynamic hand-out needs rows of >= 768 bytes and >= 16 MiB of V per workgroup.
+    const bool dyn = MODE == 1 && a.tile_ctr != nullptr && tstride == 1 && gridDim.y == 1 && !heavy && ROWB >= 768 &&
+                     ntiles * STAGE >= G * (16ll << 20) && !(HDB_MFMA_KNOCKOUT & 2);
+    constexpr int LOOK = STAGE >= 48 * 1024 ? 2 : STAGE >= 32 * 1024 ? 3 : STAGE >= 24 * 1024 ? 4 : STAGE >= 16 * 1024 ? 6 : 8;
+    const int64_t CH = 2 * LOOK, dyn0 = G * CH;
+    unsigned int* dq = ctl + 4;                      // [2] {first tile - dyn0, length} handed over by wave 3
+    const unsigned int dq_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(dq);
+    int64_t gp = 0, cidx = 0, coff = 0, cbase = 0, clen = CH, seen = 0;
+    auto gen = [&](int64_t& t, int64_t& row0, bool& valid) {     // -> tile and row0 of sequence position gp (and whether it exists)
+        if (!dyn) {
+            t = bidx + gp * G;
+            if ((HDB_MFMA_KNOCKOUT & 2) && gp >= 3) t = bidx + (gp % 3) * G;       // knock-out: stale tiles, same control flow
+            valid = bidx + gp * G < ntiles;
+        } else {
+            if (coff == 0) {
+                if (cidx == 0) { cbase = bidx * CH; clen = CH; }
+                else {
+                    unsigned long long pr;
+                    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(pr) : "v"(dq_addr + (unsigned int)(cidx & 1) * 8u) : "memory");
+                    cbase = dyn0 + (int64_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)pr);
+                    clen = (int64_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(pr >> 32));
+                }
+            }
+            if (w == 3 && coff == clen - LOOK) {                     // request the next chunk LOOK rounds before it is needed
+                const unsigned int want = ntiles - dyn0 - seen > (CH + LOOK) * G ? (unsigned int)CH : (unsigned int)LOOK;
+                unsigned int got = 0u;
+                if (lane == 0) got = __hip_atomic_fetch_add(a.tile_ctr, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                got = (unsigned int)__builtin_amdgcn_readfirstlane((int)got);
+                seen = (int64_t)got + want;
+                const unsigned long long pr = ((unsigned long long)want << 32) | got;
+                if (lane == 0) asm volatile("ds_write_b64 %0, %1" :: "v"(dq_addr + (unsigned int)((cidx + 1) & 1) * 8u), "v"(pr) : "memory");
+            }
+            t = cbase + coff;
+            valid = t < ntiles;
+            if (++coff == clen) { coff = 0; ++cidx; }
+        }
+        row0 = hdb_tile_index(t, tstride) * R;
+        ++gp;
     };
-    if (my_tiles > 0) issue(t_cur, 0);
-    if (my_tiles > 1) issue(t_cur + gstep, 1);
+    auto issue = [&](int64_t row0, int st) {
+        if (grpB) { issue_rows(row0, st); issue_aux(row0, st); }
+    };
+    int64_t tA, tB, tC = 0, rA, rB, rC = 0; bool vA, vB, vC = false;       // tile / first row / existence of sequence positions i, i+1, i+2
+    gen(tA, rA, vA);
+    gen(tB, rB, vB);
+    const bool had_tiles = vA;
+    if (vA) issue(rA, 0);
+    if (vB) issue(rB, 1);
 
     const unsigned int smem_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(smem);
     // per-lane LDS read address: row rl of a row tile; chunk (CPS*s + h) ^ rx of k-step s is at byte
@@ -335,17 +386,17 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
     Acc acc[QT][RT];
     int64_t row0_prev = 0;
     int st_cur = 0;
-    for (int64_t i = 0; i < my_tiles; ++i, t_cur += gstep) {
-        if (i + 1 >= my_tiles) hdb_wait_vmcnt<0>();
+    for (int64_t i = 0; vA; ++i) {
+        if (!vB) hdb_wait_vmcnt<0>();
         else if (grpB) hdb_wait_vmcnt<PPL + NAUX>();         // all but the newest tile's pieces are in
-        if (!(HDB_MFMA_KNOCKOUT & 4)) hdb_lds_barrier();     // tile i is in LDS; everyone is done with tile i-1
+        if (!(HDB_MFMA_KNOCKOUT & 4)) hdb_lds_barrier();     // tile i is in LDS; everyone is done with tile i-1; dq hand-over
         // Stage the whole next-but-one tile right after the barrier, into the buffer tile i-1 used.
-        const bool more = i + 2 < my_tiles;
         const int st_next2 = st_cur == 0 ? 2 : st_cur - 1;
-        if (more) issue(t_cur + 2 * gstep, st_next2);
+        if (vB) gen(tC, rC, vC); else vC = false;
+        if (vC) issue(rC, st_next2);
 
         if (wave_active) {
-            const int64_t row0 = hdb_tile_index(t_cur, tstride) * R;
+            const int64_t row0 = rA;
             if (MODE == 1 && grpB && i > 0) filter(acc, row0_prev);        // deferred epilogue of tile i-1
             // A fragments: LDS reads issued two k-steps ahead of the MFMAs that consume them.  The reads
             // and their counted waits are inline asm so that hipcc cannot sink a read next to its use
@@ -447,7 +498,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
 #pragma unroll
                             for (int j = 0; j < 4; ++j) sj[j] = hdb_canon(acc[qt][rt][4 * g + j]);
                             if (q_ok[qt]) {
-                                float* dst = a.scores + (int64_t)ql[qt] * a.ld + (t_cur * R + rl0);
+                                float* dst = a.scores + (int64_t)ql[qt] * a.ld + (tA * R + rl0);     // sample passes store compactly
                                 if (rowg + 3 < n_rows) *reinterpret_cast<float4*>(dst) = make_float4(sj[0], sj[1], sj[2], sj[3]);
                                 else {
 #pragma unroll
@@ -463,6 +514,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
             }
         }
         st_cur = st_cur == 2 ? 0 : st_cur + 1;
+        tA = tB; rA = rB; vA = vB; tB = tC; rB = rC; vB = vC;
     }
 #if HDB_MFMA_CLOCK
     {
@@ -475,7 +527,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
     }
 #endif
     if (MODE == 1) {
-        if (wave_active && grpB && my_tiles > 0) filter(acc, row0_prev);
+        if (wave_active && grpB && had_tiles) filter(acc, row0_prev);
         flush();
     }
 }

@@ -135,9 +135,10 @@ __device__ __forceinline__ uint32_t hdb_wave_max_u32(uint32_t v) {
     return v;
 }
 __global__ __launch_bounds__(1024) void hdb_sample_thr_kernel(const float* scores, int64_t n, int64_t ld, uint32_t m,
-                                                              float* thr, uint32_t* cnt) {
+                                                              float* thr, uint32_t* cnt, uint32_t* tile_ctr) {
     __shared__ uint32_t top[16 * 16];
     const int q = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (tile_ctr && q == 0 && threadIdx.x == 0) *tile_ctr = 0u;       // the filter pass's tile hand-out counter
     const float* sq = scores + (int64_t)q * ld;
     uint32_t best = 0u;                                  // key 0 is below every real score, even -inf
     const int64_t n4 = n / 4;
@@ -342,8 +343,8 @@ extern "C" int hdb_launch_thr(const uint32_t* hist, int nq, int npass, uint32_t 
     hipLaunchKernelGGL(hdb_thr_kernel, dim3(nq), dim3(64), 0, (hipStream_t)stream, hist, npass, m, sample_n, thr, cnt);
     return (int)hipGetLastError();
 }
-extern "C" int hdb_launch_sample_thr(const float* scores, int64_t n, int64_t ld, int nq, uint32_t m, float* thr, uint32_t* cnt, void* stream) {
-    hipLaunchKernelGGL(hdb_sample_thr_kernel, dim3(nq), dim3(1024), 0, (hipStream_t)stream, scores, n, ld, m, thr, cnt);
+extern "C" int hdb_launch_sample_thr(const float* scores, int64_t n, int64_t ld, int nq, uint32_t m, float* thr, uint32_t* cnt, uint32_t* tile_ctr, void* stream) {
+    hipLaunchKernelGGL(hdb_sample_thr_kernel, dim3(nq), dim3(1024), 0, (hipStream_t)stream, scores, n, ld, m, thr, cnt, tile_ctr);
     return (int)hipGetLastError();
 }
 extern "C" int hdb_launch_fill_thr(float* thr, uint32_t* cnt, int nq, float v, void* stream) {

@@ -17,7 +17,7 @@ tests)
 tests_x)
   step tests_x "${TESTSEL:-}"
   timeout -k 10 900 python -m pytest tests -m gpu -q -x -k "${TESTSEL}" > $O/gpu_tests_sel.log 2>&1; rc=$?
-  tail -15 $O/gpu_tests_sel.log; guard $rc;;
+  tail -15 $O/gpu_tests_sel.log; guard $rc; if [ $rc -ne 0 ]; then echo "selected tests failed: stopping"; exit $rc; fi;;
 clock)
   step clock
   timeout -k 10 600 python tools/clock_q256.py run $O/r2_q256_clock.json > $O/clock.log 2>&1; rc=$?
