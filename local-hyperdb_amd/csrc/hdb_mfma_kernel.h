@@ -11,7 +11,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define HDB_MFMA_CB 1024            // LDS candidate list entries per workgroup
 #define HDB_MFMA_SEG (HDB_MFMA_CB / 8)   // ... per wave
 // Measurement builds only (tools/knockout_q256.py; the product is built with 0): 1 = survivors are never appended,
-// 2 = no LDS-DMA once the ring is primed (stale but random tiles), 4 = no per-tile barrier.  Results are wrong by design.
+// 2 = no LDS-DMA once the ring is primed (stale but random tiles), 4 = no per-tile barrier, 8 = half of the fragment reads (row tiles 1 and 3 reuse 0 and 2).  Results are wrong by design.
 #ifndef HDB_MFMA_KNOCKOUT
 #define HDB_MFMA_KNOCKOUT 0
 #endif
@@ -38,6 +38,11 @@ static __device__ unsigned long long hdb_clock_buf[4 * HDB_CLOCK_WGS];
 // multiplies while A filters.  In the HBM-bound passes (up to 64 queries waves 4-7 do not multiply at all) the same
 // split gives d=384 Q=8 1.18 -> 1.12 ms, Q=64 1.30 -> 1.21, d=768 Q=64 euclidean + bias 2.54 -> 2.41, d=128 Q=48
 // 0.586 -> 0.489, N=1.25M Q=16 251 -> 214 us.
+// Later A/B on the shipped roles (256 queries, one box, 1.805-1.81 ms that day): waves 0-3 taking 3, 4, 6 or 8 twelfths of
+// the pieces and issuing them at the END of their round (after multiply and filter, while waves 4-7 multiply): 1.812,
+// 1.806, 1.807, 1.810; all twelve twelfths: 1.795 (-0.8 %).  The schedule of the staging no longer moves the pass: with
+// the staging knocked out altogether it takes 1.53 ms, with staging from L2-resident tiles 1.70 -- what is left is the
+// energy of the stream itself (HBM read + LDS write) under the power limit, see DESIGN.md section 6.
 
 #define HDB_GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 #define HDB_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -264,7 +269,6 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
     auto gen = [&](int64_t& t, int64_t& row0, bool& valid) {     // -> tile and row0 of sequence position gp (and whether it exists)
         if (!dyn) {
             t = bidx + gp * G;
-            if ((HDB_MFMA_KNOCKOUT & 2) && gp >= 3) t = bidx + (gp % 3) * G;       // knock-out: stale tiles, same control flow
             valid = bidx + gp * G < ntiles;
         } else {
             if (coff == 0) {
@@ -293,6 +297,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
         ++gp;
     };
     auto issue = [&](int64_t row0, int st) {
+        if ((HDB_MFMA_KNOCKOUT & 2) && gp > 3) return;           // knock-out: the ring keeps its first three tiles
         if (grpB) { issue_rows(row0, st); issue_aux(row0, st); }
     };
     int64_t tA, tB, tC = 0, rA, rB, rC = 0; bool vA, vB, vC = false;       // tile / first row / existence of sequence positions i, i+1, i+2
@@ -409,9 +414,9 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
             auto fetch = [&](int s, Vec (&dst)[RT]) {
                 const unsigned int ad = sb_addr + ((unsigned int)(16 * CPS * s) ^ hx);
                 asm volatile("ds_read_b128 %0, %1" : "=v"(dst[0]) : "v"(ad));
-                if constexpr (RT > 1) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[1]) : "v"(ad), "i"(RS * MF * CPR * 16));
+                if constexpr (RT > 1) { if ((HDB_MFMA_KNOCKOUT & 8) && RT == 4) dst[1] = dst[0]; else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[1]) : "v"(ad), "i"(RS * MF * CPR * 16)); }
                 if constexpr (RT > 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[2]) : "v"(ad), "i"(2 * RS * MF * CPR * 16));
-                if constexpr (RT > 3) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[3]) : "v"(ad), "i"(3 * RS * MF * CPR * 16));
+                if constexpr (RT > 3) { if (HDB_MFMA_KNOCKOUT & 8) dst[3] = dst[2]; else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[3]) : "v"(ad), "i"(3 * RS * MF * CPR * 16)); }
             };
             // wait until at most `pend` k-steps of fragment reads are outstanding: lgkmcnt(pend*RT)
             auto wait_frag = [&](int pend, Vec (&f)[RT]) {
@@ -422,7 +427,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
                     else if constexpr (RT == 2) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(f[0]), "+v"(f[1])); \
                     else asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3])); \
                 } while (0)
-                const int cnt = pend * RT;
+                const int cnt = pend * (((HDB_MFMA_KNOCKOUT & 8) && RT == 4) ? 2 : RT);
                 if (cnt >= 12) HDB_WAITF(12); else if (cnt == 8) HDB_WAITF(8); else if (cnt == 6) HDB_WAITF(6);
                 else if (cnt == 4) HDB_WAITF(4); else if (cnt == 3) HDB_WAITF(3); else if (cnt == 2) HDB_WAITF(2);
                 else if (cnt == 1) HDB_WAITF(1); else HDB_WAITF(0);

@@ -1,4 +1,4 @@
-"""A/B timing of experimental builds of the 256-query MFMA pass (HDB_MFMA_EXP bit mask, see hdb_mfma_kernel.h):
+"""A/B timing of experimental builds of the 256-query MFMA pass (HDB_MFMA_EXP, whatever hdb_mfma_kernel.h currently hangs on it):
 one library per variant, timed in interleaved rounds on one GPU (kernel time from HIP events, N=10M d=384 Q=256 dot),
 each run also checked against the single-query VALU scan for three queries.
 

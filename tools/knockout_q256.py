@@ -8,7 +8,7 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'local-hyperdb_amd', 'csrc')
 OUT = os.path.join(ROOT, 'local-hyperdb_amd', 'lib', 'knockout')
-VARIANTS = {1: "no survivor append", 2: "no LDS-DMA after priming", 3: "no append, no DMA", 7: "no append, no DMA, no barrier"}
+VARIANTS = {1: "no survivor append", 2: "no LDS-DMA after priming", 3: "no append, no DMA", 7: "no append, no DMA, no barrier", 8: "half the fragment reads", 11: "no append, no DMA, half the fragment reads"}
 CHILD = r'''
 import sys
 sys.path.insert(0, 'local-hyperdb_amd'); sys.path.insert(0, '.')
@@ -21,9 +21,9 @@ V, lo, hi = bench.make_shard(n, d, torch.float16, 0, 1, dev)
 ix = GpuIndex(V)
 Q = bench.make_queries(q, d, torch.float16, dev)
 mid = METRIC_IDS['dot_product']
-for _ in range(3): ix.topk_device(Q, 100, mid)
+for _ in range(10): ix.topk_device(Q, 100, mid)
 ix.set_option('profile', 1); torch.cuda.synchronize()
-for _ in range(8): ix.topk_device(Q, 100, mid)
+for _ in range(20): ix.topk_device(Q, 100, mid)
 torch.cuda.synchronize()
 ns, l = ix.stat('scan_time_ns'), ix.stat('scan_launches')
 print(f"kernel {ns/l/1e3:.1f} us = {2*q*n*d/(ns/l)/1e3:.0f} TFLOP/s", flush=True)
