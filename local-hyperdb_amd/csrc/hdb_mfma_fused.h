@@ -52,6 +52,7 @@ static __device__ unsigned long long hdb_fused_stamps[16 * HDB_CLOCK_WGS_F];
 #define HDB_FUSED_M 8               // sample order statistic (k <= 128)
 #define HDB_FUSED_GRAN_PER_WG 32    // HDB_FUSED_MAXQ * HDB_FUSED_M granules per workgroup
 #define HDB_FUSED_MAX_WG 1024
+#define HDB_FUSED_PEND 8            // filter tiles whose scores can be parked in LDS while no threshold is known yet
 
 
 // LDS accesses in inline asm: hipcc cannot prove them disjoint from the ring that LDS-DMA writes and would drain the
@@ -115,6 +116,13 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     float* tsc = reinterpret_cast<float*>(ctl + 16);                               // [2][MAXQ][64] scores of the latest sample tiles
     float* qpar = tsc + 2 * HDB_FUSED_MAXQ * 64;                                   // [MAXQ] multiplier, [MAXQ] NaN flag, [MAXQ] threshold
     char* qlds = smem + 2 * STAGE;                                                // prologue scratch: [nq][D] queries in E (ring slot 2, not yet in use)
+    // Parked scores (see "parking" in the tile loop): [HDB_FUSED_PEND] tiles x [queries] x [rows] floats.  The MFMA flavour
+    // (4 queries x 64 rows = 1 KiB per tile) parks in the candidate list, which is empty until a threshold exists; the
+    // float32 flavour (VQ queries x R rows) has an area of its own behind qpar.  tsc is free once the sample tiles are
+    // merged and holds the first row of each parked tile.
+    float* pbuf = VALU ? qpar + 16 : reinterpret_cast<float*>(cb);
+    static_assert(HDB_FUSED_PEND * HDB_FUSED_MAXQ * 64 * 4 <= HDB_MFMA_CB * 8, "parked MFMA scores live in the candidate list");
+    constexpr bool PARK = VALU || D <= 640;       // d = 768 would spill with it: there the selector holds the round as before
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -148,9 +156,13 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     // of its own: ~35 requests per us at N = 10M).  With a static split the slowest workgroup finished 15-25 us after the
     // median one (N = 1.25M .. 10M): that tail is what the counter removes.  Wave 3 requests the chunks and hands the
     // answers over through LDS.
-    const int64_t CH = a.ntiles >= 32 * G ? 4 : 1;   // size of the fixed chunks (and of the large requests)
-    const int64_t S = CH == 1 ? 3 : 1;
+    // The counter is one address: it answers ~70 requests per us, and G workgroups asking for ONE tile per 1.6-us round
+    // (160 / us) queue up behind it -- 3 us per tile instead of 1.7 (N = 500k: 109 us for 31 tiles per workgroup).  So
+    // requests are always for 4 tiles (2 at the very end), matrices of 8..32 tiles per workgroup take the first half of
+    // their chunks statically, and smaller ones are split statically altogether.
     const int64_t ntiles = a.ntiles;
+    const int64_t CH = ntiles >= 8 * G ? 4 : 1;      // size of the fixed chunks (and of the large requests)
+    const int64_t S = ntiles >= 32 * G ? 1 : ntiles >= 8 * G ? ntiles / (8 * G) : (ntiles + G - 1) / G;
     const int64_t dyn0 = S * G * CH;                 // first tile handed out by the counter
     unsigned int* dq = ctl + 4;                      // [2][2] {first tile - dyn0, length} handed over by wave 7
     const unsigned int dq_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(dq);
@@ -260,6 +272,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
             const float qinv = (ss == 0.f) ? 1.0f : 1.0f / sqrtf(ss);
             hdb_lds_st32(qpar_addr + (unsigned int)w * 4u, (METRIC == 1 ? qinv : 1.0f) * (1.f / scale));
             hdb_lds_st32(qpar_addr + (unsigned int)(HDB_FUSED_MAXQ + w) * 4u, (ss != ss) ? 1.f : 0.f);
+            hdb_lds_st32(qpar_addr + (unsigned int)(2 * HDB_FUSED_MAXQ + w) * 4u, __builtin_nanf(""));      // threshold: none yet
         }
     }
     hdb_lds_barrier();
@@ -351,6 +364,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     // Comparison domain of the filter == domain of the sample scores (identical arithmetic in both phases): the raw
     // dot (x 1/||v|| for cosine) without bias, the finished score with bias.
     float thr_cmp = INFINITY;
+    bool direct = false;                             // survivors straight to the global lists (while cb still holds parked scores)
     auto filter = [&](const Acc (&tv)[RT], int64_t row0) {
         float gm[RT];
 #pragma unroll
@@ -368,9 +382,9 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                         const float x = tv[rt][j];
                         if (x >= thr_cmp && rowg + j < n_rows && !(HAS_BIAS && x == -INFINITY)) {
                             const float sc = hdb_canon(HAS_BIAS ? x : x * qinv_l);
-                            unsigned int pos;
-                            asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
-                                         : "=&v"(pos) : "v"(ctl_addr), "v"(1u) : "memory");
+                            unsigned int pos = HDB_MFMA_CB;
+                            if (!(PARK && direct)) asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                                                      : "=&v"(pos) : "v"(ctl_addr), "v"(1u) : "memory");
                             if (pos < HDB_MFMA_CB) {
                                 const unsigned long long ent = hdb_pack(sc, (uint32_t)(rowg + j));
                                 asm volatile("ds_write_b64 %0, %1\n\tds_write_b16 %2, %3"
@@ -417,6 +431,9 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     // ---- selector state: the M largest sample scores of this wave's query, as orderable keys, lane r < M holds one
     uint32_t keep[2] = {0u, 0u};                     // key 0 sorts below every float, -inf included
     bool thr_final[2] = {false, false};              // every workgroup's sample went into this query's threshold
+    bool have_thr[2] = {false, false};               // some usable threshold of this query is in qpar
+    int64_t ref_at[2] = {-1, -1};                    // round (relative to nA) of the next refinement sweep
+    int ref_n[2] = {0, 0};
     bool gave_up = false;
     unsigned long long sweep_t0 = 0ull;
     auto merge_tile = [&](uint32_t& keep, unsigned int src64_addr) {      // 64 new scores, one per lane
@@ -444,6 +461,19 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     int64_t row0_prev = 0;
     bool have_prev = false;                          // wave 0: acc holds an unfiltered phase-B tile
     int thr_reads = 10;                              // wave 0 re-reads the threshold for the rounds in which sweeps can still raise it
+    bool thr_known = false;                          // every query of this call has a threshold in qpar
+    int npend = 0;                                   // parked filter tiles
+    const unsigned int pbuf_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(pbuf);
+    auto park_row0 = [&](int slot, int64_t row0) {   // first row of parked tile `slot` (tsc is free after the sample phase)
+        if (lane == 0) asm volatile("ds_write_b64 %0, %1" :: "v"(tsc_addr + (unsigned int)slot * 8u), "v"((unsigned long long)row0) : "memory");
+    };
+    auto parked_row0 = [&](int slot) {
+        unsigned long long v;
+        asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(tsc_addr + (unsigned int)slot * 8u) : "memory");
+        const unsigned int lo = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)v);
+        const unsigned int hi = (unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(v >> 32));
+        return (int64_t)(((unsigned long long)hi << 32) | lo);
+    };
     int st_cur = 0;
     for (int64_t i = 0;; ++i) {                      // the round after the last tile drains the deferred work
         const bool tile = vA;
@@ -482,32 +512,38 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                     sweep_t0 = __builtin_amdgcn_s_memrealtime();
                 }
             }
-            // first sweep right after publishing (repeated until usable), later attempts at rounds nA+3 and nA+7
+            // First sweep right after publishing, then one per round until one is usable: wave 0 parks the scores of up to
+            // HDB_FUSED_PEND filter tiles meanwhile, so the stream does not stop for the ~10 us the exchange takes; only when
+            // that budget is spent (or the stream ends) does the selector hold the round until a threshold exists.  Two
+            // refinement sweeps follow 3 and 7 rounds after the first usable one.
             const int64_t di = i - nA;
-            if (di == 0 || di == 3 || di == 7) {
+            if (di >= 0) {
 #pragma unroll
                 for (int qq = 0; qq < 2; ++qq) {
                     const int q = 2 * (w - 1) + qq;
                     if (q >= nq || thr_final[qq] || gave_up) continue;
+                    const bool first = PARK ? !have_thr[qq] : di == 0;
+                    if (PARK ? (!first && di != ref_at[qq]) : (di != 0 && di != 3 && di != 7)) continue;
+                    const bool may_skip = PARK && first && di < HDB_FUSED_PEND && vC;
                     constexpr int WPL = 64 / M;      // lane l sweeps granule (l % M) of workgroups l / M, l / M + WPL, ...
                     const int gi = lane % M, wg0 = lane / M;
                     // usable = at least 16 workgroups WITH sample rows have answered (their 8 x 16 best values put the
                     // M-th largest at ~1 % of the rows: a few extra survivors for a round or two), or everybody has
-                    const int64_t samp_wgs = f.s_tiles < G ? f.s_tiles : G;
-                    const int need_wgs = (int)(samp_wgs < 16 ? samp_wgs : 16);
+                    const int samp_wgs = (int)(f.s_tiles < G ? f.s_tiles : G);   // workgroups 0 .. samp_wgs-1 have sample tiles: only they are swept
+                    const int need_wgs = samp_wgs < 16 ? samp_wgs : 16;
                     for (;;) {
                         bool ok = true;
                         int nvalid = 0;
                         uint32_t lmax[M];            // per lane: the M largest of ITS valid granules (sorted descending)
 #pragma unroll
                         for (int r = 0; r < M; ++r) lmax[r] = 0u;
-                        constexpr int SB = 16;       // loads in flight per lane (two round trips at G = 256; 32 would spill at d = 768)
-                        for (int64_t base = wg0; base < G; base += SB * WPL) {
+                        constexpr int SB = D >= 768 && !VALU ? 8 : 16;       // loads in flight per lane (32 would spill at d = 640, 16 at d = 768)
+                        for (int base = wg0; base < samp_wgs; base += SB * WPL) {
                             unsigned long long x[SB];
 #pragma unroll
                             for (int u = 0; u < SB; ++u) {
-                                const int64_t wg = base + u * WPL;
-                                x[u] = wg < G ? __hip_atomic_load((hdb_gu64*)(f.gran + (wg * HDB_FUSED_GRAN_PER_WG + q * M + gi)),
+                                const int wg = base + u * WPL;
+                                x[u] = wg < samp_wgs ? __hip_atomic_load((hdb_gu64*)(f.gran + (wg * HDB_FUSED_GRAN_PER_WG + q * M + gi)),
                                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                               : 0ull;    // tag 0 is never an epoch
                             }
@@ -515,7 +551,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                             for (int u = 0; u < SB; ++u) {
                                 const bool tagged = (uint32_t)(x[u] >> 32) == f.epoch;
                                 uint32_t v = tagged ? (uint32_t)x[u] : 0u;
-                                if (base + u * WPL < G) { ok &= tagged; nvalid += v != 0u ? 1 : 0; }
+                                if (base + u * WPL < samp_wgs) { ok &= tagged; nvalid += v != 0u ? 1 : 0; }
 #pragma unroll
                                 for (int r = 0; r < M; ++r) { const uint32_t hi = max(lmax[r], v); v = min(lmax[r], v); lmax[r] = hi; }
                             }
@@ -541,7 +577,12 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                                 kth = v;
                             }
                             thr_final[qq] = all;
-                            if (di == 0) HDB_STAMP(3);
+                            if (first) HDB_STAMP(3);
+                            if constexpr (PARK) {
+                                have_thr[qq] = true;
+                                ref_at[qq] = ref_n[qq] == 0 ? di + 3 : ref_n[qq] == 1 ? di + 4 : -1;
+                                ++ref_n[qq];
+                            }
                             if (lane == 0) {
                                 const float thr = kth == 0u ? -INFINITY : hdb_key2f(kth);
                                 hdb_lds_st32(qpar_addr + (unsigned int)(2 * HDB_FUSED_MAXQ + q) * 4u, thr);
@@ -549,6 +590,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                             }
                             break;
                         }
+                        if (may_skip) break;             // try again next round; this round's tile gets parked
                         if (spin_expired(sweep_t0)) {    // too few workgroups answered within the timeout: give up (host falls back)
                             gave_up = true;
                             if (lane == 0) {
@@ -561,7 +603,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                     }
                 }
 #if HDB_FUSED_STAMPS
-                stamp_wave = false;
+                if (!PARK || have_thr[0] || gave_up) stamp_wave = false;
 #endif
             }
         }
@@ -570,13 +612,45 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
         if constexpr (VALU) {
         if (mfma_wave) {
             if (have_prev) {                         // deferred epilogue of tile i-1 (phase B)
-                if (thr_reads > 0) {                 // written by the selectors before this round's barrier; later sweeps raise it
+                if (!thr_known || thr_reads > 0) {   // written by the selectors before this round's barrier; later sweeps raise it
+                    float tq[VQ];
+                    bool kn = true;
+#pragma unroll
+                    for (int q = 0; q < VQ; ++q) {
+                        tq[q] = q < nq ? hdb_lds_ld32(qpar_addr + (unsigned int)(2 * HDB_FUSED_MAXQ + q) * 4u) : INFINITY;
+                        kn = kn && tq[q] == tq[q];   // NaN: no threshold yet
+                    }
+                    if (kn) {
+#pragma unroll
+                        for (int q = 0; q < VQ; ++q) if (q < nq) thr_q[q] = tq[q];
+                        thr_known = true;
+                        --thr_reads;
+                    }
+                }
+                const int u_own_p = hdb_owned_row(l16);
+                if (!thr_known) {                    // parking: keep the comparable values of this tile, filter them later
 #pragma unroll
                     for (int q = 0; q < VQ; ++q)
-                        if (q < nq) thr_q[q] = hdb_lds_ld32(qpar_addr + (unsigned int)(2 * HDB_FUSED_MAXQ + q) * 4u);
-                    --thr_reads;
+#pragma unroll
+                        for (int k2 = 0; k2 < NPW; ++k2)
+                            if (q < nq && (l16 & 3) == 0)
+                                hdb_lds_st32(pbuf_addr + (unsigned int)((npend * VQ + q) * R + 16 * (2 * k2 + pp0) + 4 * g4 + u_own_p) * 4u, pend[k2][q]);
+                    if (w == 0) park_row0(npend, row0_prev);
+                    ++npend;
+                } else {
+#pragma unroll 1
+                    for (int p = 0; p < npend; ++p) {
+                        float tv[NPW][VQ];
+#pragma unroll
+                        for (int q = 0; q < VQ; ++q)
+#pragma unroll
+                            for (int k2 = 0; k2 < NPW; ++k2)
+                                tv[k2][q] = q < nq ? hdb_lds_ld32(pbuf_addr + (unsigned int)((p * VQ + q) * R + 16 * (2 * k2 + pp0) + 4 * g4 + u_own_p) * 4u) : -INFINITY;
+                        filter_valu(tv, parked_row0(p));
+                    }
+                    npend = 0;
+                    filter_valu(pend, row0_prev);
                 }
-                filter_valu(pend, row0_prev);
                 have_prev = false;
             }
             if (tile) {
@@ -648,18 +722,50 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                 } else {
                     row0_prev = row0;
                     have_prev = true;
+#if HDB_FUSED_STAMPS
+                    { const int64_t dj = i - nA + 1; if (dj == 1) HDB_STAMP(11); else if (dj == 4) HDB_STAMP(12); else if (dj == 8) HDB_STAMP(13); else if (dj == 16) HDB_STAMP(14); else if (dj == 32) HDB_STAMP(15); }
+#endif
                 }
             }
         }
         } else {
         if (mfma_wave) {
             if (have_prev) {                         // deferred epilogue of tile i-1 (phase B)
-                if (thr_reads > 0) {                 // written by the selectors before this round's barrier; later sweeps raise it
+                if ((PARK && !thr_known) || thr_reads > 0) {   // written by the selectors before this round's barrier; later sweeps raise it
                     const float t = hdb_lds_ld32(qpar_addr + (unsigned int)(2 * HDB_FUSED_MAXQ + (q_ok ? rl : 0)) * 4u);
-                    thr_cmp = q_ok ? t : INFINITY;
-                    --thr_reads;
+                    if (!PARK || __all(t == t)) {    // NaN: some query has no threshold yet
+                        thr_cmp = q_ok ? t : INFINITY;
+                        thr_known = true;
+                        --thr_reads;
+                    }
                 }
-                filter(acc, row0_prev);
+                const unsigned int pslot = (unsigned int)(rl * 64 + 4 * h) * 4u;
+                if (PARK && !thr_known) {            // parking: keep the comparable values of this tile, filter them later
+                    if (q_ok) {
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt) hdb_lds_st128(pbuf_addr + (unsigned int)npend * 1024u + pslot + (unsigned int)rt * 64u, acc[rt]);
+                    }
+                    park_row0(npend, row0_prev);
+                    ++npend;
+                } else {
+                    if (PARK && npend > 0) {
+                        direct = true;               // the parked scores sit where the candidate list would grow
+#pragma unroll 1
+                        for (int p = 0; p < npend; ++p) {
+                            Acc tv[RT];
+#pragma unroll
+                            for (int rt = 0; rt < RT; ++rt) {
+                                f32x4 v = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                                if (q_ok) asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(pbuf_addr + (unsigned int)p * 1024u + pslot + (unsigned int)rt * 64u) : "memory");
+                                tv[rt] = v;
+                            }
+                            filter(tv, parked_row0(p));
+                        }
+                        direct = false;
+                        npend = 0;
+                    }
+                    filter(acc, row0_prev);
+                }
                 have_prev = false;
             }
             if (tile) {
@@ -733,6 +839,9 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                 } else {
                     row0_prev = row0;
                     have_prev = true;
+#if HDB_FUSED_STAMPS
+                    { const int64_t dj = i - nA + 1; if (dj == 1) HDB_STAMP(11); else if (dj == 4) HDB_STAMP(12); else if (dj == 8) HDB_STAMP(13); else if (dj == 16) HDB_STAMP(14); else if (dj == 32) HDB_STAMP(15); }
+#endif
                 }
             }
         }
@@ -792,8 +901,8 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     }
 }
 
-static size_t fused_lds_bytes(int stage_bytes) {
-    const size_t scan = mfma_lds_bytes(stage_bytes) + 2 * HDB_FUSED_MAXQ * 64 * 4 + 3 * HDB_FUSED_MAXQ * 4 + 64;
+static size_t fused_lds_bytes(int stage_bytes, size_t pend_bytes) {
+    const size_t scan = mfma_lds_bytes(stage_bytes) + 2 * HDB_FUSED_MAXQ * 64 * 4 + 16 * 4 + pend_bytes + 64;
     const size_t fin = (size_t)HDB_CAND_CAP * 16 + 2048 * 4 + 64;           // hdb_finalize_body in the last workgroup
     return scan > fin ? scan : fin;
 }
@@ -801,7 +910,7 @@ static size_t fused_lds_bytes(int stage_bytes) {
 template <typename E, int VQ, int D, int R, int METRIC, bool HAS_BIAS>
 static int launch_fused_one(const ScanArgs& a, const FusedArgs& f, const float* aux0, int blocks, hipStream_t st) {
     auto kern = hdb_mfma_fused_kernel<E, VQ, D, R, METRIC, HAS_BIAS>;
-    const size_t lds = fused_lds_bytes(R * D * (int)sizeof(E));
+    const size_t lds = fused_lds_bytes(R * D * (int)sizeof(E), sizeof(E) == 4 ? (size_t)HDB_FUSED_PEND * VQ * R * 4 : 0);
     static unsigned long long attr_done = 0;
     hipError_t e = hdb_lds_attr_once(reinterpret_cast<const void*>(kern), (int)lds, &attr_done);
     if (e != hipSuccess) return (int)e;

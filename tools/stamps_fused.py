@@ -48,10 +48,11 @@ def run():
                       ' tiles generated min/med/max:', int(a[:, 7].min()), int(np.median(a[:, 7])), int(a[:, 7].max()),
                       ' tiles of the 5 last finishers:', a[order[-5:], 7].tolist(), ' of the 5 first:', a[order[:5], 7].tolist(), flush=True)
             rows.append([wall, rel[:, 0].max(), np.median(rel[:, 1]), np.median(rel[:, 2]), rel[:, 2].max(), np.median(rel[:, 3]), rel[:, 3].max(),
-                         np.median(rel[:, 4]), rel[:, 4].max(), rel[:, 5].max(), rel[last, 6], rel[last, 5], rel[last, 8], rel[last, 9], rel[last, 10]])
+                         np.median(rel[:, 4]), rel[:, 4].max(), rel[:, 5].max(), rel[last, 6], rel[last, 5], rel[last, 8], rel[last, 9], rel[last, 10],
+                         np.median(rel[:, 11]), np.median(rel[:, 12]), np.median(rel[:, 13]), np.median(rel[:, 14]), np.median(rel[:, 15])])
         r = np.median(np.array(rows), axis=0)
         names = ['host wall', 'last start', 'prologue done (med)', 'published (med)', 'published (max)', 'thr known (med)', 'thr known (max)',
-                 'loop done (med)', 'loop done (max)', 'ticket (max)', 'finalize done', 'last WG: ticket', 'fin start', 'cands loaded', 'preselected']
+                 'loop done (med)', 'loop done (max)', 'ticket (max)', 'finalize done', 'last WG: ticket', 'fin start', 'cands loaded', 'preselected', 'filter tile 1 done (med)', 'tile 4', 'tile 8', 'tile 16', 'tile 32']
         print(f"n={n} {dt}: " + ", ".join(f"{k} {v:.1f}" for k, v in zip(names, r)), flush=True)
         ix.close(); del V; torch.cuda.empty_cache()
 
