@@ -52,7 +52,18 @@ static __device__ unsigned long long hdb_fused_stamps[16 * HDB_CLOCK_WGS_F];
 #define HDB_FUSED_M 8               // sample order statistic (k <= 128)
 #define HDB_FUSED_GRAN_PER_WG 32    // HDB_FUSED_MAXQ * HDB_FUSED_M granules per workgroup
 #define HDB_FUSED_MAX_WG 1024
-#define HDB_FUSED_PEND 8            // filter tiles whose scores can be parked in LDS while no threshold is known yet
+// Control block (FusedArgs::ctl, zero when allocated, tagged by epoch afterwards), in bytes:
+//   0   ticket, abort word, per-query candidate counts (uint32 [0..5])
+//   128 tile counter (a line of its own: ~35-70 atomics per us)
+//   256 threshold words of workgroup 0, {epoch, key & ~1 | final} per query (a line of their own: a line that takes
+//       atomics answers plain loads tens of us late)
+//   512 HDB_FUSED_POLLS copies of those words, one 128-byte line each, [selector wave][2 queries] x 8 bytes: a poller
+//       reads copy number `round`, so it never asks for a line its XCD's L2 may hold from before the words were written
+//   HDB_FUSED_HDR_BYTES  the sample granules, [workgroup][HDB_FUSED_GRAN_PER_WG] x 8 bytes
+#define HDB_FUSED_POLLS 40
+#define HDB_FUSED_HDR_BYTES 8192
+#define HDB_FUSED_PEND 8            // filter tiles whose scores can be parked in LDS while no threshold is known yet: this many for
+                                    // the most queries a flavour takes, up to 16 for fewer (same bytes)
 
 
 // LDS accesses in inline asm: hipcc cannot prove them disjoint from the ring that LDS-DMA writes and would drain the
@@ -129,6 +140,9 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     const int rl = lane & (MF - 1);
     const int h = lane / MF;
     const int nq = f.nq;
+    // parked tiles: the MFMA flavour packs nq x 64 floats per tile into the 8 KiB list, the float32 flavour VQ x R floats into its area
+    const int pend_max = VALU ? 2 * HDB_FUSED_PEND / VQ : (nq <= 2 ? 16 : 32 / nq);
+    const unsigned int pend_stride = (unsigned int)nq * 256u;      // MFMA flavour: bytes per parked tile
     const bool loader = w >= 4;                     // waves 4-7 stage the tiles
     const bool grpB = w >= 6;                       // ... 6-7 also the per-row aux values
     const int lw = w & 3;
@@ -434,6 +448,8 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     bool have_thr[2] = {false, false};               // some usable threshold of this query is in qpar
     int64_t ref_at[2] = {-1, -1};                    // round (relative to nA) of the next refinement sweep
     int ref_n[2] = {0, 0};
+    bool poll_issued = false;                        // workgroups > 0: an LDS-DMA poll of the threshold words is in flight
+    uint32_t poll_key[2] = {0u, 0u};
     bool gave_up = false;
     unsigned long long sweep_t0 = 0ull;
     auto merge_tile = [&](uint32_t& keep, unsigned int src64_addr) {      // 64 new scores, one per lane
@@ -460,7 +476,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     Acc acc[RT];
     int64_t row0_prev = 0;
     bool have_prev = false;                          // wave 0: acc holds an unfiltered phase-B tile
-    int thr_reads = 10;                              // wave 0 re-reads the threshold for the rounds in which sweeps can still raise it
+    int thr_reads = 24;                              // wave 0 re-reads the threshold for the rounds in which refinements can still raise it
     bool thr_known = false;                          // every query of this call has a threshold in qpar
     int npend = 0;                                   // parked filter tiles
     const unsigned int pbuf_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(pbuf);
@@ -518,13 +534,58 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
             // refinement sweeps follow 3 and 7 rounds after the first usable one.
             const int64_t di = i - nA;
             if (di >= 0) {
+                // workgroups > 0: the two threshold words of this wave's queries as the LDS-DMA poll of the previous round left
+                // them in LDS (16 bytes, one lane, one request: a word cannot tear)
+                unsigned long long pollw[2] = {0ull, 0ull};          // tag 0 is never an epoch
+                const unsigned int poll_addr = tsc_addr + 1024u + (unsigned int)(w - 1) * 16u;
+                if (b != 0 && poll_issued) {
+                    asm volatile("s_waitcnt vmcnt(0)\n\tds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(pollw[0]), "=&v"(pollw[1]) : "v"(poll_addr) : "memory");
+                    poll_issued = false;
+                }
 #pragma unroll
                 for (int qq = 0; qq < 2; ++qq) {
                     const int q = 2 * (w - 1) + qq;
                     if (q >= nq || thr_final[qq] || gave_up) continue;
+                    hdb_gu64* const word = (hdb_gu64*)(f.ctl + 64 + 2 * q);       // {epoch, key & ~1 | final}: workgroup 0's result (a cache line of their own)
+                    if (b != 0) {
+                        // Every workgroup but the first POLLS one word per query instead of sweeping the granules itself: a
+                        // sweep is ~3 us of loads behind the CU's own staging traffic and stretched each round it ran in from
+                        // 1.7 to 3.2 us (five of them per call).  The poll is an LDS-DMA load issued in one round and looked at
+                        // in the next (pollw, see below), so a round never waits for it; only when the parking budget is
+                        // spent does the wave spin on the word itself.
+                        const bool first = !have_thr[qq];
+                        const bool may_skip = PARK && first && di < pend_max && vC;
+                        unsigned long long v = pollw[qq];
+                        for (;;) {
+                            if ((uint32_t)(v >> 32) == f.epoch) {
+                                const uint32_t key = (uint32_t)v & ~1u;
+                                if (first || key != poll_key[qq]) {
+                                    if (lane == 0) hdb_lds_st32(qpar_addr + (unsigned int)(2 * HDB_FUSED_MAXQ + q) * 4u, key == 0u ? -INFINITY : hdb_key2f(key));
+                                    poll_key[qq] = key;
+                                }
+                                if (first) HDB_STAMP(3);
+                                have_thr[qq] = true;
+                                thr_final[qq] = ((uint32_t)v & 1u) != 0u;
+                                break;
+                            }
+                            if (may_skip || !first) break;
+                            if (spin_expired(sweep_t0)) {
+                                gave_up = true;
+                                if (lane == 0) {
+                                    hdb_lds_st32(qpar_addr + (unsigned int)(2 * HDB_FUSED_MAXQ + q) * 4u, INFINITY);
+                                    atomicOr(&f.ctl[1], 1u);
+                                }
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(2);
+                            v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        continue;
+                    }
                     const bool first = PARK ? !have_thr[qq] : di == 0;
                     if (PARK ? (!first && di != ref_at[qq]) : (di != 0 && di != 3 && di != 7)) continue;
-                    const bool may_skip = PARK && first && di < HDB_FUSED_PEND && vC;
+                    const bool may_skip = PARK && first && di < pend_max && vC;
                     constexpr int WPL = 64 / M;      // lane l sweeps granule (l % M) of workgroups l / M, l / M + WPL, ...
                     const int gi = lane % M, wg0 = lane / M;
                     // usable = at least 16 workgroups WITH sample rows have answered (their 8 x 16 best values put the
@@ -537,7 +598,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                         uint32_t lmax[M];            // per lane: the M largest of ITS valid granules (sorted descending)
 #pragma unroll
                         for (int r = 0; r < M; ++r) lmax[r] = 0u;
-                        constexpr int SB = D >= 768 && !VALU ? 8 : 16;       // loads in flight per lane (32 would spill at d = 640, 16 at d = 768)
+                        constexpr int SB = VALU ? 16 : 8;       // loads in flight per lane (fp16 flavour: wave 0 holds the B fragments, registers are short)
                         for (int base = wg0; base < samp_wgs; base += SB * WPL) {
                             unsigned long long x[SB];
 #pragma unroll
@@ -586,8 +647,13 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                             if (lane == 0) {
                                 const float thr = kth == 0u ? -INFINITY : hdb_key2f(kth);
                                 hdb_lds_st32(qpar_addr + (unsigned int)(2 * HDB_FUSED_MAXQ + q) * 4u, thr);
-                                if (b == 0 && all) f.thr_out[q] = thr;
+                                if (all) f.thr_out[q] = thr;
+                                // for everybody else; the low key bit carries "final" (a key rounded down is a lower threshold: safe)
+                                __hip_atomic_store(word, ((unsigned long long)f.epoch << 32) | (kth & ~1u) | (all ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             }
+                            if (lane < HDB_FUSED_POLLS)      // ... and the copies the pollers read, one per round
+                                __hip_atomic_store((hdb_gu64*)(reinterpret_cast<char*>(f.ctl) + 512 + lane * 128 + (w - 1) * 16 + qq * 8),
+                                                   ((unsigned long long)f.epoch << 32) | (kth & ~1u) | (all ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             break;
                         }
                         if (may_skip) break;             // try again next round; this round's tile gets parked
@@ -602,8 +668,15 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                         __builtin_amdgcn_s_sleep(2);
                     }
                 }
+                // next poll (copy number `di`): while a final threshold is still to come, for at most HDB_FUSED_POLLS rounds
+                if (b != 0 && !gave_up && di < HDB_FUSED_POLLS && ((2 * (w - 1) < nq && !thr_final[0]) || (2 * (w - 1) + 1 < nq && !thr_final[1]))) {
+                    if (lane == 0)
+                        __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(reinterpret_cast<const char*>(f.ctl) + 512 + di * 128 + (w - 1) * 16),
+                                                         HDB_LDS_PTR(tsc + 256 + 4 * (w - 1)), 16, 0, 16 /* sc1: agent scope */);
+                    poll_issued = true;
+                }
 #if HDB_FUSED_STAMPS
-                if (!PARK || have_thr[0] || gave_up) stamp_wave = false;
+                if ((!PARK && b == 0) || have_thr[0] || gave_up) stamp_wave = false;
 #endif
             }
         }
@@ -743,7 +816,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                 if (PARK && !thr_known) {            // parking: keep the comparable values of this tile, filter them later
                     if (q_ok) {
 #pragma unroll
-                        for (int rt = 0; rt < RT; ++rt) hdb_lds_st128(pbuf_addr + (unsigned int)npend * 1024u + pslot + (unsigned int)rt * 64u, acc[rt]);
+                        for (int rt = 0; rt < RT; ++rt) hdb_lds_st128(pbuf_addr + (unsigned int)npend * pend_stride + pslot + (unsigned int)rt * 64u, acc[rt]);
                     }
                     park_row0(npend, row0_prev);
                     ++npend;
@@ -756,7 +829,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
 #pragma unroll
                             for (int rt = 0; rt < RT; ++rt) {
                                 f32x4 v = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-                                if (q_ok) asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(pbuf_addr + (unsigned int)p * 1024u + pslot + (unsigned int)rt * 64u) : "memory");
+                                if (q_ok) asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(pbuf_addr + (unsigned int)p * pend_stride + pslot + (unsigned int)rt * 64u) : "memory");
                                 tv[rt] = v;
                             }
                             filter(tv, parked_row0(p));
@@ -910,7 +983,7 @@ static size_t fused_lds_bytes(int stage_bytes, size_t pend_bytes) {
 template <typename E, int VQ, int D, int R, int METRIC, bool HAS_BIAS>
 static int launch_fused_one(const ScanArgs& a, const FusedArgs& f, const float* aux0, int blocks, hipStream_t st) {
     auto kern = hdb_mfma_fused_kernel<E, VQ, D, R, METRIC, HAS_BIAS>;
-    const size_t lds = fused_lds_bytes(R * D * (int)sizeof(E), sizeof(E) == 4 ? (size_t)HDB_FUSED_PEND * VQ * R * 4 : 0);
+    const size_t lds = fused_lds_bytes(R * D * (int)sizeof(E), sizeof(E) == 4 ? (size_t)2 * HDB_FUSED_PEND * R * 4 : 0);
     static unsigned long long attr_done = 0;
     hipError_t e = hdb_lds_attr_once(reinterpret_cast<const void*>(kern), (int)lds, &attr_done);
     if (e != hipSuccess) return (int)e;

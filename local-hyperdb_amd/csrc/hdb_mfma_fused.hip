@@ -12,7 +12,7 @@ extern "C" int hdb_mfma_fused_supported(int dtype, int d, int metric, int nq, ui
 }
 
 // bytes of the persistent control block: 64 words of counters + the granules
-extern "C" size_t hdb_mfma_fused_ctl_bytes(void) { return 256 + (size_t)HDB_FUSED_MAX_WG * HDB_FUSED_GRAN_PER_WG * 8; }
+extern "C" size_t hdb_mfma_fused_ctl_bytes(void) { return HDB_FUSED_HDR_BYTES + (size_t)HDB_FUSED_MAX_WG * HDB_FUSED_GRAN_PER_WG * 8; }
 
 extern "C" int hdb_launch_mfma_fused(const ScanArgs* args, int dtype, const FusedArgs* fa, int max_blocks, void* stream) {
     const ScanArgs& a = *args;
@@ -23,7 +23,7 @@ extern "C" int hdb_launch_mfma_fused(const ScanArgs* args, int dtype, const Fuse
     if (max_blocks > 0 && max_blocks < blocks) blocks = max_blocks;
     if (blocks > HDB_FUSED_MAX_WG) blocks = HDB_FUSED_MAX_WG;
     if (blocks < 1) blocks = 1;
-    f.gran = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(f.ctl) + 256);
+    f.gran = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(f.ctl) + HDB_FUSED_HDR_BYTES);
     if (dtype == HDB_F32) {
         switch (a.d) {
             case 128: return f.nq == 1 ? launch_fused<float, 1, 128, 64>(a, f, blocks, st) : launch_fused<float, 2, 128, 64>(a, f, blocks, st);

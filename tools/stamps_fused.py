@@ -28,7 +28,8 @@ def run():
     lib = _native.lib()
     lib.hdb_debug_read_fused_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
     for (n, dt) in ((1_250_000, torch.float16), (10_000_000, torch.float16), (1_000_000, torch.float32)):
-        V, lo, hi = bench.make_shard(n, 384, dt, 0, 1, dev)
+      V, lo, hi = bench.make_shard(n, 384, dt, 0, 1, dev)
+      for unc in (0,):
         ix = GpuIndex(V)
         Q = bench.make_queries(64, 384, dt, dev).to(torch.float32)
         mid = METRIC_IDS['cosine_similarity']
@@ -43,6 +44,7 @@ def run():
             rel = (a - t_start) / 100.0          # us
             last = int(np.argmax(a[:, 6]))
             if i == 39:
+                print('   thr known: WG0', round(float(rel[0, 3]), 1), 'percentiles', [round(float(np.percentile(rel[1:, 3], p)), 1) for p in (0, 10, 50, 90, 100)], 'published WG0', round(float(rel[0, 2]), 1), flush=True)
                 order = np.argsort(rel[:, 4])
                 print('   per-WG loop-done percentiles (us):', [round(float(np.percentile(rel[:, 4], p)), 1) for p in (0, 10, 50, 90, 99, 100)],
                       ' tiles generated min/med/max:', int(a[:, 7].min()), int(np.median(a[:, 7])), int(a[:, 7].max()),
@@ -54,7 +56,8 @@ def run():
         names = ['host wall', 'last start', 'prologue done (med)', 'published (med)', 'published (max)', 'thr known (med)', 'thr known (max)',
                  'loop done (med)', 'loop done (max)', 'ticket (max)', 'finalize done', 'last WG: ticket', 'fin start', 'cands loaded', 'preselected', 'filter tile 1 done (med)', 'tile 4', 'tile 8', 'tile 16', 'tile 32']
         print(f"n={n} {dt}: " + ", ".join(f"{k} {v:.1f}" for k, v in zip(names, r)), flush=True)
-        ix.close(); del V; torch.cuda.empty_cache()
+        ix.close()
+      del V; torch.cuda.empty_cache()
 
 if __name__ == '__main__':
     {'build': build, 'run': run}[sys.argv[1]]()
