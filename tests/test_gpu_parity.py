@@ -1287,6 +1287,48 @@ def test_single_launch_pipeline_failure_paths(ranking, orc):
         ix.close()
 
 
+@pytest.mark.parametrize("dt", [np.float16, np.float32])
+def test_single_launch_pipeline_winners_in_parked_tiles(orc, dt):
+    """The first filter tiles of every workgroup are scored before any threshold exists and parked in LDS
+    (hdb_mfma_fused.h, "parking").  (a) every winner sits in such a tile: the 128 best rows are scattered over the first
+    65 536 rows (the first chunk of each workgroup), the rest of the matrix is in random order, so the row sample stays
+    representative and the call must succeed in the single launch; (b) rows sorted by descending score: the strided tile
+    sample then sees the very best rows, the threshold lands above the k-th best, the call reports UNDERFLOW and the host
+    entry re-runs it exactly -- either way the caller gets the exact top-k."""
+    import torch
+    from hyperdb._native import GpuIndex, METRIC_IDS
+    rng = np.random.default_rng(2024)
+    n, d = (600_000, 384) if dt == np.float16 else (300_000, 384)
+    V = rng.standard_normal((n, d)).astype(np.float32).astype(dt)
+    q = rng.standard_normal(d).astype(np.float32).astype(dt).astype(np.float32)
+    order = np.argsort(-(V.astype(np.float32) @ q), kind="stable")
+    head = np.sort(rng.choice(65_536, size=128, replace=False))
+    rest = np.setdiff1d(np.arange(n), head, assume_unique=True)
+    scattered = np.empty_like(V)
+    scattered[head] = V[order[:128]]
+    scattered[rest] = V[order[128:][rng.permutation(n - 128)]]
+    clean = 0
+    for M in (scattered, np.ascontiguousarray(V[order])):
+        ix = GpuIndex(M)
+        try:
+            for metric in ("dot_product", "cosine_similarity"):
+                mid = METRIC_IDS[metric]
+                for k in (1, 100, 128):
+                    fi, fs, st = ix.topk_device(q.reshape(1, -1), k, mid)
+                    assert ix.stat("fused") == 1
+                    ei, es, _ = ix.topk_device(q.reshape(1, -1), k, mid, exact=True)
+                    if int(st.abs().sum().item()) == 0:
+                        assert torch.equal(fi, ei) and torch.equal(fs, es), (metric, k)
+                        clean += M is scattered
+                    hi, hs = ix.topk(q.reshape(1, -1), k, mid)          # host entry: re-runs what the launch could not settle
+                    assert np.array_equal(hi[0], ei[0].cpu().numpy()) and np.array_equal(hs[0], es[0].cpu().numpy()), (metric, k)
+            idx, sc = ix.topk(q.reshape(1, -1), 100, METRIC_IDS["dot_product"])
+            orc.check_topk(idx[0], sc[0], M, q, "dot_product", 100, tol=1e-3 if dt == np.float16 else 1e-5)
+        finally:
+            ix.close()
+    assert clean == 6, "the scattered layout must be settled by the single launch itself"
+
+
 @pytest.mark.parametrize("n,d", [(8193, 384), (70_001, 128), (250_000, 256), (400_003, 384)])
 def test_single_launch_pipeline_float32(orc, n, d):
     """float32 matrices (the reference's default fp_precision, BASELINE config 2): 1-2 dot / cosine queries run as one launch
