@@ -198,7 +198,9 @@ void hdb_group_destroy(hdb_group* g);
  *   host_direct (0: hdb_topk_host always copies through a device record), exact_bytes (score workspace cap of
  *   the exact path), finalize_threads (256 | 512 | 1024), profile (1: HIP events around the pass over V),
  *   use_fused (0: never the single-launch pipeline), fused_timeout_us (bound of its in-kernel spins, default 2000),
- *   host_poll (0: hdb_topk_host always waits on the stream instead of polling the status words of a pinned record).
+ *   host_poll (0: hdb_topk_host always waits on the stream instead of polling the status words of a pinned record),
+ *   dyn_tiles (0: the batched MFMA filter pass always splits its tiles statically; default 1 = tiles from a counter for
+ *   long passes over rows of >= 768 bytes with up to 64 queries).
  *   max_blocks < 0 asks for -max_blocks workgroups per CU in the batched MFMA scan (measured: no gain).
  * Stats:    path (0 small, 1 sampled threshold, 2 exact, 3 full sort), mfma, fused, host_direct, chunks, sample_rows, sample_m,
  *   scan_launches, scan_time_ns (sum over the profiled launches), cand_cap, n, ws_bytes. */

@@ -15,12 +15,14 @@
 //             LDS buffer; waves 1..nq ("selectors", otherwise only staging) keep the m largest sample scores of their
 //             query in registers (m rounds of wave-max extraction per tile).
 //   exchange  each selector publishes its m values as 8-byte {epoch, value} granules (one sc1 store per lane; the
-//             data is its own flag) and sweeps the G x m granules of its query until every tag carries this call's
-//             epoch: an all-gather without a grid barrier, ~3 us, during which the staging of the first tiles of
-//             phase B is already in flight.  The m-th largest of the gathered values is the EXACT m-th largest
-//             sample score: the per-query threshold, computed redundantly by every workgroup.
-//   phase B   the filter pass over all rows (the only pass over V); wave 0 defers the epilogue of a tile by one
-//             tile, so the threshold is first needed one tile after the exchange started.
+//             data is its own flag).  Workgroup 0 sweeps the granules of the workgroups that have sample tiles until
+//             enough of them carry this call's epoch -- an all-gather without a grid barrier -- and stores the m-th
+//             largest as one {epoch, key | final} word per query; every other workgroup polls that word (an LDS-DMA
+//             load issued one round, looked at the next).  The m-th largest of ALL sample values is the exact sample
+//             threshold; of a subset, a lower bound of it that is already safe to filter with.
+//   parking   until its threshold arrives wave 0 keeps the scores of its filter tiles in LDS (up to 16 tiles) and
+//             filters them in one go afterwards: the stream never stops for the exchange.
+//   phase B   the filter pass over all rows (the only pass over V); wave 0 defers the epilogue of a tile by one tile.
 //   finish    survivors go to the global candidate lists (atomics); each workgroup drains, releases and takes a
 //             ticket; the LAST workgroup re-uses the ring LDS to pre-select, sort and write the k results (and the
 //             status words) of every query, straight into the caller's (pinned host or device) buffers.
