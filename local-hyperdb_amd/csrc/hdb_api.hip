@@ -637,7 +637,8 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
         FusedArgs fa; memset(&fa, 0, sizeof(fa));
         fa.Qraw = static_cast<const float*>(dev_Q); fa.nq = nq;
         fa.s_tiles = s_tiles; fa.s_stride = s_stride;
-        if (++ix->fused_epoch == 0) ix->fused_epoch = 1;
+        ix->fused_epoch = (ix->fused_epoch + 1) & 0x7FFFFFFFu;          // 31 bits: bit 31 of a tag is the "final" flag of the threshold words
+        if (ix->fused_epoch == 0) ix->fused_epoch = 1;
         fa.epoch = ix->fused_epoch;
         fa.timeout_ticks = (uint32_t)std::min<int64_t>(ix->fused_timeout_us * 100, 0x7FFFFFFF);
         fa.ctl = reinterpret_cast<uint32_t*>(ix->fctl);

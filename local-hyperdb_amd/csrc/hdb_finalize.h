@@ -94,17 +94,32 @@ static __device__ uint32_t hdb_preselect(unsigned long long* buf, uint32_t nc, u
 // buf (cap u64) | scratch (cap u64) | hist (2048 u32) | ctl (8 u32) = cap*16 + 8224 bytes.  `total` = number of
 // candidates that were appended (may exceed cap: overflow); extra_status is OR-ed into the status word.
 // Called by hdb_finalize_kernel (one workgroup per query) and by the last workgroup of the fused scan kernel.
-__device__ __forceinline__ void hdb_finalize_body(unsigned long long* buf, const unsigned long long* cand, uint32_t total, int q,
-                                                  uint32_t cap, uint32_t k, uint32_t kk /* min(k, n) */, int64_t row_base,
-                                                  int64_t* idx_out, float* score_out, int32_t* status, int qnan_flag,
-                                                  int32_t extra_status) {
+// With `count_above` the function returns, to every thread, how many of the loaded candidates have a score key ABOVE
+// floor_key (ctl word 8; the list may hold entries that only some workgroups collected, see hdb_mfma_fused.h); else 0.
+__device__ __forceinline__ uint32_t hdb_finalize_body(unsigned long long* buf, const unsigned long long* cand, uint32_t total, int q,
+                                                      uint32_t cap, uint32_t k, uint32_t kk /* min(k, n) */, int64_t row_base,
+                                                      int64_t* idx_out, float* score_out, int32_t* status, int qnan_flag,
+                                                      int32_t extra_status, bool count_above = false, uint32_t floor_key = 0u) {
     unsigned long long* scratch = buf + cap;
     uint32_t* hist = reinterpret_cast<uint32_t*>(scratch + cap);
-    uint32_t* ctl = hist + 2048;
+    uint32_t* ctl = hist + 2048;                    // 16 words
     const uint32_t nc = total < cap ? total : cap;
     HDB_FIN_STAMP(8);
-    for (uint32_t i = threadIdx.x; i < nc; i += blockDim.x) buf[i] = cand[i];      // `cand` = this query's list
-    __syncthreads();
+    uint32_t n_above = 0;
+    if (count_above) {
+        if (threadIdx.x == 0) ctl[8] = 0;
+        __syncthreads();
+        uint32_t mine = 0;
+        for (uint32_t i = threadIdx.x; i < nc; i += blockDim.x) { const unsigned long long e = cand[i]; buf[i] = e; mine += (uint32_t)(e >> 32) > floor_key ? 1u : 0u; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+        if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&ctl[8], mine);
+        __syncthreads();
+        n_above = ctl[8];
+    } else {
+        for (uint32_t i = threadIdx.x; i < nc; i += blockDim.x) buf[i] = cand[i];      // `cand` = this query's list
+        __syncthreads();
+    }
     HDB_FIN_STAMP(9);
     uint32_t ns = nc;
     if (nc > 512 && kk < nc / 2) ns = hdb_preselect(buf, nc, kk, hist, scratch, ctl);
@@ -152,5 +167,6 @@ __device__ __forceinline__ void hdb_finalize_body(unsigned long long* buf, const
         if (qnan_flag) st |= HDB_Q_NAN;
         status[q] = st;
     }
+    return n_above;
 }
 

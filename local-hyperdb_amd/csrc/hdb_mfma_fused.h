@@ -17,7 +17,7 @@
 //   exchange  each selector publishes its m values as 8-byte {epoch, value} granules (one sc1 store per lane; the
 //             data is its own flag).  Workgroup 0 sweeps the granules of the workgroups that have sample tiles until
 //             enough of them carry this call's epoch -- an all-gather without a grid barrier -- and stores the m-th
-//             largest as one {epoch, key | final} word per query; every other workgroup polls that word (an LDS-DMA
+//             largest as one {final | epoch, key} word per query; every other workgroup polls that word (an LDS-DMA
 //             load issued one round, looked at the next).  The m-th largest of ALL sample values is the exact sample
 //             threshold; of a subset, a lower bound of it that is already safe to filter with.
 //   parking   until its threshold arrives wave 0 keeps the scores of its filter tiles in LDS (up to 16 tiles) and
@@ -57,7 +57,7 @@ static __device__ unsigned long long hdb_fused_stamps[16 * HDB_CLOCK_WGS_F];
 // Control block (FusedArgs::ctl, zero when allocated, tagged by epoch afterwards), in bytes:
 //   0   ticket, abort word, per-query candidate counts (uint32 [0..5])
 //   128 tile counter (a line of its own: ~35-70 atomics per us)
-//   256 threshold words of workgroup 0, {epoch, key & ~1 | final} per query (a line of their own: a line that takes
+//   256 threshold words of workgroup 0, {final << 31 | epoch, key} per query (a line of their own: a line that takes
 //       atomics answers plain loads tens of us late)
 //   512 HDB_FUSED_POLLS copies of those words, one 128-byte line each, [selector wave][2 queries] x 8 bytes: a poller
 //       reads copy number `round`, so it never asks for a line its XCD's L2 may hold from before the words were written
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                 for (int qq = 0; qq < 2; ++qq) {
                     const int q = 2 * (w - 1) + qq;
                     if (q >= nq || thr_final[qq] || gave_up) continue;
-                    hdb_gu64* const word = (hdb_gu64*)(f.ctl + 64 + 2 * q);       // {epoch, key & ~1 | final}: workgroup 0's result (a cache line of their own)
+                    hdb_gu64* const word = (hdb_gu64*)(f.ctl + 64 + 2 * q);       // {final << 31 | epoch, key}: workgroup 0's result (a cache line of their own)
                     if (b != 0) {
                         // Every workgroup but the first POLLS one word per query instead of sweeping the granules itself: a
                         // sweep is ~3 us of loads behind the CU's own staging traffic and stretched each round it ran in from
@@ -560,15 +560,15 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                         const bool may_skip = PARK && first && di < pend_max && vC;
                         unsigned long long v = pollw[qq];
                         for (;;) {
-                            if ((uint32_t)(v >> 32) == f.epoch) {
-                                const uint32_t key = (uint32_t)v & ~1u;
+                            if (((uint32_t)(v >> 32) & 0x7FFFFFFFu) == f.epoch) {
+                                const uint32_t key = (uint32_t)v;
                                 if (first || key != poll_key[qq]) {
                                     if (lane == 0) hdb_lds_st32(qpar_addr + (unsigned int)(2 * HDB_FUSED_MAXQ + q) * 4u, key == 0u ? -INFINITY : hdb_key2f(key));
                                     poll_key[qq] = key;
                                 }
                                 if (first) HDB_STAMP(3);
                                 have_thr[qq] = true;
-                                thr_final[qq] = ((uint32_t)v & 1u) != 0u;
+                                thr_final[qq] = (v >> 63) != 0ull;
                                 break;
                             }
                             if (may_skip || !first) break;
@@ -646,16 +646,17 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                                 ref_at[qq] = ref_n[qq] == 0 ? di + 3 : ref_n[qq] == 1 ? di + 4 : -1;
                                 ++ref_n[qq];
                             }
+                            const unsigned long long pubw = ((unsigned long long)(f.epoch | (all ? 0x80000000u : 0u)) << 32) | kth;
                             if (lane == 0) {
                                 const float thr = kth == 0u ? -INFINITY : hdb_key2f(kth);
                                 hdb_lds_st32(qpar_addr + (unsigned int)(2 * HDB_FUSED_MAXQ + q) * 4u, thr);
-                                if (all) f.thr_out[q] = thr;
-                                // for everybody else; the low key bit carries "final" (a key rounded down is a lower threshold: safe)
-                                __hip_atomic_store(word, ((unsigned long long)f.epoch << 32) | (kth & ~1u) | (all ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                f.thr_out[q] = thr;              // the highest threshold anybody filters with (read by the last workgroup)
+                                // for everybody else; bit 31 of the tag carries "final" (epochs are 31 bits wide)
+                                __hip_atomic_store(word, pubw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             }
                             if (lane < HDB_FUSED_POLLS)      // ... and the copies the pollers read, one per round
                                 __hip_atomic_store((hdb_gu64*)(reinterpret_cast<char*>(f.ctl) + 512 + lane * 128 + (w - 1) * 16 + qq * 8),
-                                                   ((unsigned long long)f.epoch << 32) | (kth & ~1u) | (all ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                                   pubw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             break;
                         }
                         if (may_skip) break;             // try again next round; this round's tile gets parked
@@ -949,8 +950,20 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
         unsigned long long* fbuf = reinterpret_cast<unsigned long long*>(smem);     // the ring is free now
         const unsigned int aborted = __hip_atomic_load(f.ctl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned int qnan_bits = 0u;
+        // Workgroups filter with thresholds that only rise (provisional, then refined): the list may hold rows that only
+        // some of them collected.  What is guaranteed complete is everything at or above the LAST threshold workgroup 0
+        // published (nobody used a higher one), so the top-k is exact iff at least kk candidates score above it -- counting
+        // all candidates would let the extras hide an underflow (clustered rows in a sample tile: 72 above, 100+ collected).
+        uint32_t floor_key[HDB_FUSED_MAXQ];
 #pragma unroll
-        for (int q = 0; q < HDB_FUSED_MAXQ; ++q) if (q < nq && qpar[HDB_FUSED_MAXQ + q] != 0.f) qnan_bits |= 1u << q;
+        for (int q = 0; q < HDB_FUSED_MAXQ; ++q) {
+            floor_key[q] = 0u;
+            if (q < nq) {
+                if (qpar[HDB_FUSED_MAXQ + q] != 0.f) qnan_bits |= 1u << q;
+                const float t = __hip_atomic_load(f.thr_out + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                floor_key[q] = hdb_f2key(hdb_canon(HAS_BIAS ? t : t * qpar[q]));       // score domain of the packed entries
+            }
+        }
         __syncthreads();                             // everyone has its copy: fbuf may now cover ctl / qpar
         // The status words are written LAST, behind a system-scope release: a host that polls them in a pinned record
         // (hdb_topk_host) may read the results as soon as every word has left its sentinel value.
@@ -959,11 +972,15 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
         for (int q = 0; q < nq; ++q) {
             const uint32_t tot0 = __hip_atomic_load(f.ctl + 2 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t tot = aborted ? 0u : tot0;
-            hdb_finalize_body(fbuf, f.cand + (int64_t)q * f.cap, tot, q, f.cap, f.k, f.kk, f.row_base, f.idx_out, f.score_out,
-                              nullptr, 0, 0);
+            uint32_t fk = 0u;
+#pragma unroll
+            for (int qq = 0; qq < HDB_FUSED_MAXQ; ++qq) if (qq == q) fk = floor_key[qq];
+            const uint32_t n_above = hdb_finalize_body(fbuf, f.cand + (int64_t)q * f.cap, tot, q, f.cap, f.k, f.kk, f.row_base, f.idx_out,
+                                                       f.score_out, nullptr, 0, 0, true, fk);
             if (tid == q) {
                 const uint32_t nc = tot < f.cap ? tot : f.cap;
-                my_status = (tot > f.cap ? HDB_Q_OVERFLOW : 0) | (nc < f.kk ? HDB_Q_UNDERFLOW : 0) | (((qnan_bits >> q) & 1u) ? HDB_Q_NAN : 0);
+                const uint32_t need = f.kk < nc ? f.kk : nc;         // fewer than kk rows in all (mask): nc < kk reports that
+                my_status = (tot > f.cap ? HDB_Q_OVERFLOW : 0) | ((nc < f.kk || n_above < need) ? HDB_Q_UNDERFLOW : 0) | (((qnan_bits >> q) & 1u) ? HDB_Q_NAN : 0);
             }
             __syncthreads();
         }

@@ -1287,6 +1287,76 @@ def test_single_launch_pipeline_failure_paths(ranking, orc):
         ix.close()
 
 
+@pytest.mark.parametrize("dt,n,d,nq", [(np.float16, 50_282, 512, 4), (np.float16, 19_201, 256, 1), (np.float32, 43_279, 256, 2),
+                                        (np.float16, 700_001, 384, 3)])
+def test_single_launch_pipeline_threshold_minus_inf(dt, n, d, nq):
+    """A row mask that leaves 5 % of the rows (or a bias of -inf on the rest) leaves fewer than 8 finite scores in the row
+    sample: the sampled threshold is -inf, every unmasked row is a candidate, and every workgroup -- the one that computes
+    the threshold and the ones that are told -- must filter with exactly that (a -inf that came back as NaN from the
+    exchange once parked every tile of the other workgroups for good)."""
+    import torch
+    from hyperdb._native import GpuIndex, METRIC_IDS
+    g = torch.Generator(device="cuda").manual_seed(n + d)
+    V = torch.randn((n, d), generator=g, device="cuda").to(torch.float16 if dt == np.float16 else torch.float32)
+    Q = torch.randn((nq, d), generator=g, device="cuda").to(V.dtype).float()
+    ix = GpuIndex(V)
+    try:
+        for keep in (0.05, 0.004):
+            ix.set_row_mask((torch.rand(n, generator=g, device="cuda") < keep).to(torch.uint8))
+            for with_bias in (False, True):
+                ix.set_bias((torch.rand(n, generator=g, device="cuda") * 0.3).float() if with_bias else None)
+                for metric in ("cosine_similarity", "dot_product"):
+                    for k in (1, 5, 100):
+                        mid = METRIC_IDS[metric]
+                        fi, fs, st = ix.topk_device(Q, k, mid)
+                        assert ix.stat("fused") == 1
+                        ei, es, _ = ix.topk_device(Q, k, mid, exact=True)
+                        for q in range(nq):
+                            if int(st[q].item()) == 0:
+                                assert torch.equal(fi[q], ei[q]) and torch.equal(fs[q], es[q]), (keep, with_bias, metric, k, q)
+                        hi, hs = ix.topk(Q, k, mid)
+                        assert np.array_equal(hi, ei.cpu().numpy()) and np.array_equal(hs, es.cpu().numpy()), (keep, with_bias, metric, k)
+    finally:
+        ix.close()
+
+
+@pytest.mark.parametrize("dt,n,d", [(np.float32, 549_592, 128), (np.float16, 700_000, 384)])
+def test_single_launch_pipeline_cluster_in_a_sample_tile(dt, n, d):
+    """300 near-copies of one row, queried with that row: when the cluster falls into a tile of the row sample the
+    threshold lands inside the cluster and fewer than k rows pass it.  Workgroups that filtered some tiles with an
+    earlier, lower threshold collect extra rows, so the candidate list can still hold k entries -- the call must report
+    UNDERFLOW from the rows above the LAST threshold, not from the length of the list (found by tools/fuzz_fused.py:
+    72 rows above, 100+ collected, status 0, ranks 72.. wrong)."""
+    import torch
+    from hyperdb._native import GpuIndex, METRIC_IDS
+    g = torch.Generator(device="cuda").manual_seed(n)
+    V = torch.randn((n, d), generator=g, device="cuda").to(torch.float16 if dt == np.float16 else torch.float32)
+    noise = torch.randn((300, d), generator=g, device="cuda")
+    mid = METRIC_IDS["cosine_similarity"]
+    flagged = 0
+    ix = GpuIndex(V)
+    try:
+        for trial in range(150):
+            c0 = (trial * 9001 + 17) % (n - 300)
+            saved = V[c0:c0 + 300].clone()
+            V[c0:c0 + 300] = (saved[0:1].float() + 0.05 * noise).to(V.dtype)
+            ix.update(V)
+            q = V[c0].float().reshape(1, -1)
+            fi, fs, st = ix.topk_device(q, 100, mid)
+            assert ix.stat("fused") == 1
+            ei, es, _ = ix.topk_device(q, 100, mid, exact=True)
+            if int(st[0].item()) == 0:
+                assert torch.equal(fi, ei) and torch.equal(fs, es), (trial, c0)
+            else:
+                flagged += 1
+                hi, hs = ix.topk(q, 100, mid)
+                assert np.array_equal(hi, ei.cpu().numpy()) and np.array_equal(hs, es.cpu().numpy()), (trial, c0)
+            V[c0:c0 + 300] = saved
+    finally:
+        ix.close()
+    assert flagged >= 1, "no trial put the cluster into a sample tile: move the clusters"
+
+
 @pytest.mark.parametrize("dt", [np.float16, np.float32])
 def test_single_launch_pipeline_winners_in_parked_tiles(orc, dt):
     """The first filter tiles of every workgroup are scored before any threshold exists and parked in LDS
