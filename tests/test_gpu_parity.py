@@ -1113,6 +1113,45 @@ def test_config4_100m_rows_eight_shards_merge_equals_single_index(orc):
         torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("n,d,nq,metric", [(6_000_001, 384, 17, "cosine_similarity"), (3_000_017, 768, 40, "dot_product"),
+                                            (1_500_001, 1536, 33, "euclidean_metric")])
+def test_batched_filter_pass_tiles_from_a_counter(n, d, nq, metric):
+    """Long filter passes over rows of >= 768 bytes with up to 64 queries take their tiles from a global counter
+    (hdb_mfma_kernel.h, "tile sequence") instead of the static split: same candidates, so the same result bit for bit,
+    with and without a bias, ragged last tile included; and both equal the on-device exact selection."""
+    import torch
+    import bench
+    from hyperdb._native import GpuIndex, METRIC_IDS
+    dev = torch.device("cuda", 0)
+    V, _, _ = bench.make_shard(n, d, torch.float16, 0, 1, dev)
+    V[n - 1] = V[5]                                         # the ragged last tile holds a row that ties with an early one
+    Q = bench.make_queries(nq, d, torch.float16, dev).float()
+    Q[1] = V[5].float()
+    g = torch.Generator(device=dev).manual_seed(n)
+    ix = GpuIndex(V)
+    try:
+        mid = METRIC_IDS[metric]
+        for with_bias in (False, True):
+            ix.set_bias((torch.rand(n, generator=g, device=dev) * 0.05).float() if with_bias else None)
+            ix.set_option("dyn_tiles", 1)
+            di, ds, dst = ix.topk_device(Q, 100, mid)
+            assert ix.stat("mfma") == 1 and ix.stat("path") == 1 and int(dst.abs().sum().item()) == 0
+            ix.set_option("dyn_tiles", 0)
+            si, ss, sst = ix.topk_device(Q, 100, mid)
+            ix.set_option("dyn_tiles", 1)
+            assert int(sst.abs().sum().item()) == 0 and torch.equal(di, si) and torch.equal(ds, ss), with_bias
+            ei, es, _ = ix.topk_device(Q[:6], 100, mid, exact=True)
+            if metric == "euclidean_metric":                # near-duplicates are re-scored directly on the filter path only
+                sa, sb = torch.sort(ds[:6], dim=-1, descending=True)[0], torch.sort(es, dim=-1, descending=True)[0]
+                assert bool(((sa - sb).abs() <= 1e-6 * sa.abs().clamp(min=1e-3)).all())
+            else:
+                assert torch.equal(di[:6], ei) and torch.equal(ds[:6], es), with_bias
+    finally:
+        ix.close()
+        del V
+        torch.cuda.empty_cache()
+
+
 def test_config5_full_size_euclidean_with_time_decay(orc):
     """Config 5 at full size: N=10M d=768 fp16, 64 queries, euclidean similarity + recency term (timestamps uniform
     over 30 days, recency_bias 0.5).  MFMA pass vs float64 scores of the returned rows (all 64 queries), vs the VALU
