@@ -11,8 +11,10 @@ A step is one query call of the hot path over the whole stored matrix: metric sc
 + top-100, results copied back to the host (what HyperDB.query() does per call).  The matrix is
 resident in HBM before the timed region (synthetic standard-normal rows, seeded per 250k-row block so
 shards are identical for every GPU count).  With N GPUs the 10M rows are row-sharded (strong
-scaling: total work fixed); each rank scans its shard, the per-shard top-100 lists are exchanged with
-ONE RCCL all-gather and merged on every rank.
+scaling: total work fixed); each rank scans its shard and the per-shard top-100 records (1.2 KB) are exchanged ONCE per
+query and merged on every rank: on one node through a shared-memory swap of the host records every rank produces anyway
+(hyperdb/sharded.py HostExchange + hdb_merge_topk_host), records above 64 KiB (the Q=256 leg) and HDB_EXCHANGE=collective
+through ONE RCCL all-gather + the merge kernel.
 
 One JSON line is printed by rank 0.  Besides the contract fields it carries
   roofline      -- dominant kernel (the pass over all of V) timed with HIP events on its launch
@@ -317,7 +319,8 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if args.dtype == "fp32" else "f16", "data": "synthetic",
             "config": {"workload": f"N={args.n} d={args.d} {args.dtype} Q=1 {args.metric} top-{args.k}, row-sharded x{world}",
-                       "rows_per_gpu": hi - lo, "accumulate": "f32", "exchange": "none" if world == 1 else "1 RCCL all-gather of packed top-k per query"},
+                       "rows_per_gpu": hi - lo, "accumulate": "f32", "exchange": "none" if world == 1 else ("shared-memory swap of the ranks' host records + host merge, once per query"
+                                                                   if sharded._hx is not None else "1 RCCL all-gather of packed top-k per query + merge kernel")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": headline_kernel, "kernel_us": kern_s * 1e6,
@@ -328,6 +331,7 @@ def main():
         if extras:
             out["extra"] = extras
         print(json.dumps(out))
+    sharded.close()
     if dist:
         dist.destroy_process_group()
 

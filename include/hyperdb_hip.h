@@ -168,6 +168,21 @@ int hdb_merge_topk(const int64_t* dev_idx_parts, const float* dev_score_parts, i
 int64_t hdb_packed_bytes(int32_t nq, int32_t k);
 int hdb_merge_topk_packed(const void* dev_gathered, int32_t parts, int32_t nq, int32_t k, int64_t* dev_idx,
                           float* dev_score, int32_t* dev_status, int device, void* stream);
+/* The same merge on the HOST, for records that are already in host memory (one process per GPU on one node: every rank's
+ * hdb_topk_host leaves its record in host memory, the ranks swap the 1.2 KB records through a shared-memory segment and
+ * merge here -- a few microseconds instead of a collective, a merge launch and another synchronisation).  `records` =
+ * `parts` packed records back to back (shard p's rows precede shard p+1's), `out_record` = one packed record; same total
+ * order (score descending, global row ascending), status words OR-ed per query, missing entries -1 / -inf.  No GPU call. */
+int hdb_merge_topk_host(const void* records, int32_t parts, int32_t nq, int32_t k, void* out_record);
+/* The swap itself, for `world` processes of one node that have all mapped the same zero-initialised shared-memory segment
+ * `shm` of 2 * world * stride bytes (hyperdb/sharded.py HostExchange creates it): slot (parity, rank) = 64-byte header
+ * {seq} + record.  Exchange number seq (1, 2, ... in lockstep on every rank) copies `record` (hdb_packed_bytes(nq, k)
+ * bytes, <= stride - 64) into this rank's slot of parity seq & 1, publishes seq behind it (release), waits until every
+ * rank's slot carries seq (acquire; HDB_ERR_HIP after timeout_s) and merges the `world` records straight out of the
+ * segment into out_record like hdb_merge_topk_host.  A slot is rewritten two exchanges later, which no rank can reach
+ * before everybody has published the exchange in between, i.e. has finished reading this one.  No GPU call. */
+int hdb_host_exchange_merge(void* shm, int64_t stride, int32_t world, int32_t rank, uint64_t seq, const void* record,
+                            int32_t nq, int32_t k, void* out_record, double timeout_s);
 
 /* Single-process multi-GPU group: HyperDB.query() (hyperdb.py:1584) is a single-process
  * call, so the row-sharded matrix must be reachable without a launcher.  A group is `parts` row shards, each an hdb_index

@@ -722,6 +722,70 @@ extern "C" int hdb_topk(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k,
 
 extern "C" int64_t hdb_packed_bytes(int32_t nq, int32_t k);
 
+// k-way merge of `parts` packed records in host memory (recs[p] = record of shard p) into out_record
+static void merge_host_records(const char* const* recs, int32_t parts, int32_t nq, int32_t k, void* out_record) {
+    int64_t* oi = reinterpret_cast<int64_t*>(out_record);
+    float* os = reinterpret_cast<float*>(static_cast<char*>(out_record) + (int64_t)nq * k * 8);
+    int32_t* ost = reinterpret_cast<int32_t*>(static_cast<char*>(out_record) + (int64_t)nq * k * 12);
+    std::vector<int32_t> pos((size_t)parts);
+    for (int32_t q = 0; q < nq; ++q) {
+        int32_t st = 0;
+        for (int32_t p = 0; p < parts; ++p) {
+            st |= reinterpret_cast<const int32_t*>(recs[p] + (int64_t)nq * k * 12)[q];
+            pos[p] = 0;
+        }
+        for (int32_t i = 0; i < k; ++i) {                // lists sorted by (score descending, row ascending)
+            int32_t best = -1; int64_t bi = -1; float bs = 0.f;
+            for (int32_t p = 0; p < parts; ++p) {
+                if (pos[p] >= k) continue;
+                const int64_t ci = reinterpret_cast<const int64_t*>(recs[p])[(int64_t)q * k + pos[p]];
+                if (ci < 0) { pos[p] = k; continue; }    // padding: this shard has no more rows
+                const float cs = reinterpret_cast<const float*>(recs[p] + (int64_t)nq * k * 8)[(int64_t)q * k + pos[p]];
+                if (best < 0 || cs > bs || (cs == bs && ci < bi)) { best = p; bi = ci; bs = cs; }
+            }
+            if (best < 0) { oi[(int64_t)q * k + i] = -1; os[(int64_t)q * k + i] = -INFINITY; }
+            else { oi[(int64_t)q * k + i] = bi; os[(int64_t)q * k + i] = bs; ++pos[best]; }
+        }
+        ost[q] = st;
+    }
+}
+
+extern "C" int hdb_merge_topk_host(const void* records, int32_t parts, int32_t nq, int32_t k, void* out_record) {
+    if (!records || !out_record || parts <= 0 || nq < 0 || k < 0) return fail(HDB_ERR_ARG, "hdb_merge_topk_host: bad argument");
+    const int64_t nb = hdb_packed_bytes(nq, k);
+    std::vector<const char*> recs((size_t)parts);
+    for (int32_t p = 0; p < parts; ++p) recs[p] = static_cast<const char*>(records) + p * nb;
+    merge_host_records(recs.data(), parts, nq, k, out_record);
+    return HDB_OK;
+}
+
+extern "C" int hdb_host_exchange_merge(void* shm, int64_t stride, int32_t world, int32_t rank, uint64_t seq, const void* record,
+                                       int32_t nq, int32_t k, void* out_record, double timeout_s) {
+    if (!shm || !record || !out_record || world <= 0 || rank < 0 || rank >= world || stride < 64 || nq < 0 || k < 0)
+        return fail(HDB_ERR_ARG, "hdb_host_exchange_merge: bad argument");
+    const int64_t nb = hdb_packed_bytes(nq, k);
+    if (nb + 64 > stride) return fail(HDB_ERR_ARG, "hdb_host_exchange_merge: record larger than a slot");
+    char* base = static_cast<char*>(shm) + (int64_t)(seq & 1) * world * stride;
+    char* mine = base + (int64_t)rank * stride;
+    memcpy(mine + 64, record, (size_t)nb);
+    __atomic_store_n(reinterpret_cast<uint64_t*>(mine), seq, __ATOMIC_RELEASE);          // publish: after the data
+    std::vector<const char*> recs((size_t)world);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int32_t r = 0; r < world; ++r) {
+        const uint64_t* sp = reinterpret_cast<const uint64_t*>(base + (int64_t)r * stride);
+        uint32_t spins = 0;
+        while (__atomic_load_n(sp, __ATOMIC_ACQUIRE) != seq) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFFu) == 0 &&
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s)
+                return fail(HDB_ERR_HIP, "hdb_host_exchange_merge: a rank did not publish its record in time");
+        }
+        recs[r] = base + (int64_t)r * stride + 64;
+    }
+    merge_host_records(recs.data(), world, nq, k, out_record);
+    return HDB_OK;
+}
+
 extern "C" int hdb_topk_host(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, int metric, void* host_record, void* stream) {
     if (!ix || !host_record) return fail(HDB_ERR_ARG, "hdb_topk_host: null argument");
     if (nq <= 0 || k <= 0) return fail(HDB_ERR_ARG, "hdb_topk_host: nq and k must be positive");

@@ -94,32 +94,26 @@ static __device__ uint32_t hdb_preselect(unsigned long long* buf, uint32_t nc, u
 // buf (cap u64) | scratch (cap u64) | hist (2048 u32) | ctl (8 u32) = cap*16 + 8224 bytes.  `total` = number of
 // candidates that were appended (may exceed cap: overflow); extra_status is OR-ed into the status word.
 // Called by hdb_finalize_kernel (one workgroup per query) and by the last workgroup of the fused scan kernel.
-// With `count_above` the function returns, to every thread, how many of the loaded candidates have a score key ABOVE
-// floor_key (ctl word 8; the list may hold entries that only some workgroups collected, see hdb_mfma_fused.h); else 0.
+// With `floor_ptr` the function returns, to every thread, whether the kk-th best candidate scores ABOVE
+// canon(*floor_ptr * floor_mul), i.e. whether at least kk candidates do (the list may hold entries that only some
+// workgroups collected, see hdb_mfma_fused.h; ctl word 8).  The load of *floor_ptr overlaps the candidate loads.
 __device__ __forceinline__ uint32_t hdb_finalize_body(unsigned long long* buf, const unsigned long long* cand, uint32_t total, int q,
                                                       uint32_t cap, uint32_t k, uint32_t kk /* min(k, n) */, int64_t row_base,
                                                       int64_t* idx_out, float* score_out, int32_t* status, int qnan_flag,
-                                                      int32_t extra_status, bool count_above = false, uint32_t floor_key = 0u) {
+                                                      int32_t extra_status, const float* floor_ptr = nullptr, float floor_mul = 1.f) {
     unsigned long long* scratch = buf + cap;
     uint32_t* hist = reinterpret_cast<uint32_t*>(scratch + cap);
     uint32_t* ctl = hist + 2048;                    // 16 words
     const uint32_t nc = total < cap ? total : cap;
     HDB_FIN_STAMP(8);
-    uint32_t n_above = 0;
-    if (count_above) {
+    float floor_v = 0.f;
+    if (floor_ptr) {
+        floor_v = __hip_atomic_load(floor_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (threadIdx.x == 0) ctl[8] = 0;
-        __syncthreads();
-        uint32_t mine = 0;
-        for (uint32_t i = threadIdx.x; i < nc; i += blockDim.x) { const unsigned long long e = cand[i]; buf[i] = e; mine += (uint32_t)(e >> 32) > floor_key ? 1u : 0u; }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
-        if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&ctl[8], mine);
-        __syncthreads();
-        n_above = ctl[8];
-    } else {
-        for (uint32_t i = threadIdx.x; i < nc; i += blockDim.x) buf[i] = cand[i];      // `cand` = this query's list
-        __syncthreads();
     }
+    for (uint32_t i = threadIdx.x; i < nc; i += blockDim.x) buf[i] = cand[i];      // `cand` = this query's list
+    __syncthreads();
+    const uint32_t floor_key = floor_ptr ? hdb_f2key(hdb_canon(floor_v * floor_mul)) : 0u;
     HDB_FIN_STAMP(9);
     uint32_t ns = nc;
     if (nc > 512 && kk < nc / 2) ns = hdb_preselect(buf, nc, kk, hist, scratch, ctl);
@@ -142,6 +136,7 @@ __device__ __forceinline__ uint32_t hdb_finalize_body(unsigned long long* buf, c
                 idx_out[(int64_t)q * k + rank] = row_base + (int64_t)(0xFFFFFFFFu - (uint32_t)(mine & 0xFFFFFFFFull));
                 score_out[(int64_t)q * k + rank] = hdb_key2f((uint32_t)(mine >> 32));
             }
+            if (floor_ptr && rank == kk - 1) ctl[8] = (uint32_t)(mine >> 32) > floor_key ? 1u : 0u;      // the kk-th best
         }
     } else {
     int P = 64;
@@ -149,6 +144,7 @@ __device__ __forceinline__ uint32_t hdb_finalize_body(unsigned long long* buf, c
     for (int i = ns + threadIdx.x; i < P; i += blockDim.x) buf[i] = 0ull;
     __syncthreads();
     hdb_bitonic_desc(buf, P);
+    if (floor_ptr && threadIdx.x == 0 && nc >= kk && kk > 0) ctl[8] = (uint32_t)(buf[kk - 1] >> 32) > floor_key ? 1u : 0u;
     for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
         if (i < nc && i < kk) {
             const unsigned long long e = buf[i];
@@ -167,6 +163,8 @@ __device__ __forceinline__ uint32_t hdb_finalize_body(unsigned long long* buf, c
         if (qnan_flag) st |= HDB_Q_NAN;
         status[q] = st;
     }
-    return n_above;
+    uint32_t kth_above = 0;
+    if (floor_ptr) { __syncthreads(); kth_above = ctl[8]; }
+    return kth_above;
 }
 

@@ -954,14 +954,13 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
         // some of them collected.  What is guaranteed complete is everything at or above the LAST threshold workgroup 0
         // published (nobody used a higher one), so the top-k is exact iff at least kk candidates score above it -- counting
         // all candidates would let the extras hide an underflow (clustered rows in a sample tile: 72 above, 100+ collected).
-        uint32_t floor_key[HDB_FUSED_MAXQ];
+        float floor_mul[HDB_FUSED_MAXQ];             // thr_out is in the comparison domain: x this = score domain of the entries
 #pragma unroll
         for (int q = 0; q < HDB_FUSED_MAXQ; ++q) {
-            floor_key[q] = 0u;
+            floor_mul[q] = 1.f;
             if (q < nq) {
                 if (qpar[HDB_FUSED_MAXQ + q] != 0.f) qnan_bits |= 1u << q;
-                const float t = __hip_atomic_load(f.thr_out + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                floor_key[q] = hdb_f2key(hdb_canon(HAS_BIAS ? t : t * qpar[q]));       // score domain of the packed entries
+                if (!HAS_BIAS) floor_mul[q] = qpar[q];
             }
         }
         __syncthreads();                             // everyone has its copy: fbuf may now cover ctl / qpar
@@ -972,15 +971,14 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
         for (int q = 0; q < nq; ++q) {
             const uint32_t tot0 = __hip_atomic_load(f.ctl + 2 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t tot = aborted ? 0u : tot0;
-            uint32_t fk = 0u;
+            float fm = 1.f;
 #pragma unroll
-            for (int qq = 0; qq < HDB_FUSED_MAXQ; ++qq) if (qq == q) fk = floor_key[qq];
-            const uint32_t n_above = hdb_finalize_body(fbuf, f.cand + (int64_t)q * f.cap, tot, q, f.cap, f.k, f.kk, f.row_base, f.idx_out,
-                                                       f.score_out, nullptr, 0, 0, true, fk);
+            for (int qq = 0; qq < HDB_FUSED_MAXQ; ++qq) if (qq == q) fm = floor_mul[qq];
+            const uint32_t kth_above = hdb_finalize_body(fbuf, f.cand + (int64_t)q * f.cap, tot, q, f.cap, f.k, f.kk, f.row_base, f.idx_out,
+                                                       f.score_out, nullptr, 0, 0, f.thr_out + q, fm);
             if (tid == q) {
                 const uint32_t nc = tot < f.cap ? tot : f.cap;
-                const uint32_t need = f.kk < nc ? f.kk : nc;         // fewer than kk rows in all (mask): nc < kk reports that
-                my_status = (tot > f.cap ? HDB_Q_OVERFLOW : 0) | ((nc < f.kk || n_above < need) ? HDB_Q_UNDERFLOW : 0) | (((qnan_bits >> q) & 1u) ? HDB_Q_NAN : 0);
+                my_status = (tot > f.cap ? HDB_Q_OVERFLOW : 0) | ((nc < f.kk || (f.kk > 0 && !kth_above)) ? HDB_Q_UNDERFLOW : 0) | (((qnan_bits >> q) & 1u) ? HDB_Q_NAN : 0);
             }
             __syncthreads();
         }

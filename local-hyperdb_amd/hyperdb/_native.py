@@ -38,7 +38,7 @@ EXPORTS = (
     "hdb_group_create", "hdb_group_topk_host", "hdb_group_destroy",
     "hdb_index_has_nan", "hdb_index_set_bias", "hdb_index_set_row_mask", "hdb_scores", "hdb_topk",
     "hdb_topk_exact", "hdb_merge_topk", "hdb_set_option", "hdb_get_stat", "hdb_recency_bias",
-    "hdb_packed_bytes", "hdb_merge_topk_packed", "hdb_topk_host",
+    "hdb_packed_bytes", "hdb_merge_topk_packed", "hdb_merge_topk_host", "hdb_host_exchange_merge", "hdb_topk_host",
 )
 
 
@@ -81,6 +81,8 @@ def _load():
     lib.hdb_topk_host.argtypes = [vp, vp, i32, i32, ctypes.c_int, vp, vp]
     lib.hdb_packed_bytes.argtypes = [i32, i32]
     lib.hdb_merge_topk_packed.argtypes = [vp, i32, i32, i32, vp, vp, vp, ctypes.c_int, vp]
+    lib.hdb_merge_topk_host.argtypes = [vp, i32, i32, i32, vp]
+    lib.hdb_host_exchange_merge.argtypes = [vp, i64, i32, i32, ctypes.c_uint64, vp, i32, i32, vp, ctypes.c_double]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("hdb_last_error", "hdb_index_destroy", "hdb_group_destroy", "hdb_packed_bytes"):
@@ -405,6 +407,13 @@ class GpuIndex:
                                   _stream_ptr(self.device)), "hdb_topk_host")
         return slot[2], slot[3], slot[4]
 
+    def topk_record_host(self, Q, k, metric_id):
+        """topk_views, but returns the whole packed record as ONE uint8 numpy view (what a shard hands to the exchange)."""
+        qt = self._query_tensor(Q, batched=True)
+        nq = int(qt.shape[0])
+        self.topk_views(qt, k, metric_id)
+        return self._host_records[(nq, int(k))][0].numpy()
+
     def topk(self, Q, k, metric_id):
         """Top-k of a query batch on the host: (int64 [nq,k], float32 [nq,k]) (copies)."""
         idx, sc, st = self.topk_views(Q, k, metric_id)
@@ -440,6 +449,31 @@ def record_to_host(record, nq, k, cache):
     sc = h[nq * k * 8:nq * k * 12].view(np.float32).reshape(nq, k)
     st = h[nq * k * 12:nq * k * 12 + nq * 4].view(np.int32)
     return idx, sc, st
+
+
+def record_views(h, nq, k):
+    """numpy views (idx int64 [nq,k], score float32 [nq,k], status int32 [nq]) of a packed record held in a uint8 array."""
+    return (h[:nq * k * 8].view(np.int64).reshape(nq, k), h[nq * k * 8:nq * k * 12].view(np.float32).reshape(nq, k),
+            h[nq * k * 12:nq * k * 12 + nq * 4].view(np.int32))
+
+
+def merge_topk_host(records, parts, nq, k, out):
+    """hdb_merge_topk_host: `records` = parts packed records back to back in HOST memory (uint8 numpy), `out` = uint8
+    numpy of packed_bytes(nq, k).  Pure host code (no GPU call).  Returns the views of `out`."""
+    nb = packed_bytes(nq, k)
+    if records.dtype != np.uint8 or records.size < parts * nb or out.dtype != np.uint8 or out.size < nb:
+        raise ValueError("merge_topk_host: records / out must be uint8 arrays of parts * packed_bytes / packed_bytes")
+    if not (records.flags["C_CONTIGUOUS"] and out.flags["C_CONTIGUOUS"]):
+        raise ValueError("merge_topk_host: contiguous arrays only")
+    _check(_lib.hdb_merge_topk_host(ctypes.c_void_p(records.ctypes.data), int(parts), int(nq), int(k),
+                                    ctypes.c_void_p(out.ctypes.data)), "hdb_merge_topk_host")
+    return record_views(out, nq, k)
+
+
+def host_exchange_merge(shm_addr, stride, world, rank, seq, record_addr, nq, k, out_addr, timeout_s):
+    """hdb_host_exchange_merge on raw addresses (the caller caches them: this sits on the per-query path)."""
+    _check(_lib.hdb_host_exchange_merge(shm_addr, stride, world, rank, seq, record_addr, nq, k, out_addr, timeout_s),
+           "hdb_host_exchange_merge")
 
 
 def merge_topk_packed_into(gathered, parts, nq, k, out_record):

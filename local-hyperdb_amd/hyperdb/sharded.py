@@ -8,6 +8,12 @@ so the only exchange step is the gather of each shard's k best (SURVEY.md sectio
     torch.distributed.all_gather_into_tensor (backend "nccl" == RCCL over xGMI; payload = nq*k*12 B per rank)
     hdb_merge_topk_packed on every rank   ->  identical global top-k everywhere
 
+On ONE node (the launch model of bench.py: one process per GPU of a node) records of up to 64 KiB per rank do not take
+the collective: every rank's hdb_topk_host leaves its record in host memory anyway (the answer is for the host), so the
+ranks swap records through a shared-memory segment (HostExchange: sequence-tagged slots, two parities) and merge with
+hdb_merge_topk_host -- ~5 us instead of a collective + a merge launch + another stream synchronisation (>= 30 us at 1.2 KB).
+Larger batches, several nodes, or HDB_EXCHANGE=collective keep the all-gather.
+
 Ordering is the build's total order (score descending, global row ascending), so the result does not
 depend on the number of shards.  Queries whose sampled threshold failed on ANY shard (status != 0 in
 the gathered records, seen identically by all ranks) are re-run through the exact path collectively.
@@ -26,6 +32,100 @@ try:
     import torch.distributed as dist
 except Exception:  # pragma: no cover
     dist = None
+
+
+class HostExchangeUnavailable(RuntimeError):
+    """Raised on EVERY rank of the group when the shared-memory segment could not be set up on some rank."""
+
+
+class HostExchange:
+    """All-gather of small host records between the ranks of ONE node through a file in /dev/shm that every rank maps.
+
+    Layout: [parity 0 | parity 1] x [rank] x (64-byte header {seq u64} + slot_bytes).  Exchange number s uses parity s & 1:
+    a rank copies its record into its slot, then stores seq = s (release), then spins until every slot of that parity
+    carries s (acquire) and merges the records straight out of the segment -- all inside hdb_host_exchange_merge.  A slot
+    is rewritten two exchanges later, and nobody can be two exchanges ahead of a rank that has not published the one in
+    between, so readers never see a slot change under them.
+    The file is unlinked as soon as every rank has mapped it: nothing is left behind, whatever happens to the processes."""
+    HEADER = 64
+
+    def __init__(self, group, rank, world, device, slot_bytes=65536, timeout_s=120.0):
+        import mmap
+        import os
+        import time
+        self.rank, self.world, self.slot_bytes, self.timeout_s = rank, world, int(slot_bytes), float(timeout_s)
+        self._time = time
+        stride = self.HEADER + self.slot_bytes
+        total = 2 * world * stride
+        # the file name travels as a number in a tensor broadcast (plain collectives only: they are what RCCL / gloo do best)
+        tag = torch.zeros(1, dtype=torch.int64, device=device)
+        if rank == 0:
+            tag[0] = (time.time_ns() ^ (os.getpid() << 20)) & 0x7FFFFFFFFFFFFFFF
+        src = dist.get_global_rank(group, 0) if (group is not None and hasattr(dist, "get_global_rank")) else 0
+        dist.broadcast(tag, src=src, group=group)
+        name = f"/dev/shm/hdb_x_{int(tag.item()):x}"
+
+        def agreed(ok):                               # every rank learns whether the step worked everywhere (also the barrier)
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            return bool(flag.item())
+
+        fd, ok = -1, True
+        if rank == 0:
+            try:
+                fd = os.open(name, os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)
+                os.ftruncate(fd, total)
+            except OSError:
+                ok = False
+        if not agreed(ok):                            # the file exists -- or nobody goes on
+            if fd >= 0:
+                os.close(fd)
+                os.unlink(name)
+            raise HostExchangeUnavailable("rank 0 could not create the shared-memory segment")
+        self._mm = None
+        try:
+            if rank != 0:
+                fd = os.open(name, os.O_RDWR)
+            self._mm = mmap.mmap(fd, total)
+        except (OSError, ValueError):
+            ok = False
+        if fd >= 0:
+            os.close(fd)
+        everybody = agreed(ok)                        # everybody has mapped it -- or nobody uses it
+        if rank == 0:
+            os.unlink(name)
+        if not everybody:
+            if self._mm is not None:
+                self._mm.close()
+            raise HostExchangeUnavailable("a rank could not map the shared-memory segment")
+        import ctypes
+        self._stride = stride
+        self._cobj = ctypes.c_char.from_buffer(self._mm)
+        self._addr = ctypes.addressof(self._cobj)      # for hdb_host_exchange_merge
+        self._out = {}                                # (nq, k) -> (uint8 array, its address, its views)
+        self._count = 0
+
+    def exchange_merge(self, record, nq, k):
+        """One C call (hdb_host_exchange_merge): publish this rank's packed record (uint8 numpy, host memory), wait for the
+        others, merge all of them -> views (idx, score, status) of the merged record (overwritten by the next call with the
+        same shape)."""
+        from . import _native
+        slot = self._out.get((nq, k))
+        if slot is None:
+            out = np.empty(_native.packed_bytes(nq, k), dtype=np.uint8)
+            slot = self._out[(nq, k)] = (out, out.ctypes.data, _native.record_views(out, nq, k))
+        self._count += 1
+        _native.host_exchange_merge(self._addr, self._stride, self.world, self.rank, self._count, record.ctypes.data, nq, k,
+                                    slot[1], self.timeout_s)
+        return slot[2]
+
+    def close(self):
+        self._cobj = None
+        self._addr = None
+        try:
+            self._mm.close()
+        except BufferError:                           # an exported pointer is still alive: the mapping goes with the process
+            pass
 
 
 class HipEngine:
@@ -88,6 +188,15 @@ class HipEngine:
     def topk_host(self, Q, k, metric_id):
         return self.index.topk_views(Q, k, metric_id)
 
+    def topk_record_host(self, Q, k, metric_id, exact=False):
+        """This shard's packed record in HOST memory (uint8 numpy view, overwritten by the next call)."""
+        if not exact:
+            return self.index.topk_record_host(Q, k, metric_id)      # one C call; a failed threshold is re-run inside it
+        nq = int(Q.shape[0])                             # (rare: only when another shard still reported a failure)
+        rec = self.new_record(self.packed_bytes(nq, k), 0)
+        self.index.topk_packed(Q, k, metric_id, rec, exact=True)
+        return rec.cpu().numpy()
+
     def select_queries(self, Q, which):
         return Q.index_select(0, torch.as_tensor(which, device=Q.device))
 
@@ -104,13 +213,48 @@ def shard_bounds(n_total, world, granule=1):
 
 
 class ShardedIndex:
-    def __init__(self, local, n_total=None, group=None, engine=None, force_exchange=False):
+    def __init__(self, local, n_total=None, group=None, engine=None, force_exchange=False, exchange=None):
+        """exchange: "host" (shared-memory swap of host records + host merge; one node only), "collective" (all-gather of
+        device records + merge kernel) or None = $HDB_EXCHANGE, else "host" when every rank runs on this node."""
+        import os
         self.engine = engine if engine is not None else HipEngine(local)
         self.group = group
         self.world = dist.get_world_size(group) if (group is not None and dist is not None) else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.n_total = n_total
         self.force_exchange = force_exchange and group is not None     # run gather+merge even with one rank (tests)
+        self._hx = None
+        mode = exchange or os.environ.get("HDB_EXCHANGE") or "auto"
+        if mode not in ("host", "collective", "auto"):
+            raise ValueError("exchange must be 'host', 'collective' or None")
+        if self.world > 1 and mode != "collective" and hasattr(self.engine, "topk_record_host"):
+            import socket
+            import zlib
+            dev = self._coll_device()
+            mine = torch.tensor([zlib.crc32(socket.gethostname().encode())], dtype=torch.int64, device=dev)
+            hosts = torch.zeros(self.world, dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(hosts, mine, group=group)
+            if bool((hosts == hosts[0]).all().item()):
+                try:
+                    self._hx = HostExchange(group, self.rank, self.world, dev)
+                except HostExchangeUnavailable:       # raised on every rank alike: all of them keep the collective
+                    if mode == "host":
+                        raise
+            elif mode == "host":
+                raise ValueError("exchange='host' needs every rank on one node")
+
+    def _coll_device(self):
+        """Where the tensors of the small bookkeeping collectives live: the engine's device under RCCL, the host under gloo."""
+        try:
+            backend = str(dist.get_backend(self.group))
+        except Exception:
+            backend = "nccl"
+        return torch.device("cpu") if backend == "gloo" else self.engine.device
+
+    def close(self):
+        if self._hx is not None:
+            self._hx.close()
+            self._hx = None
 
     # -- helpers -------------------------------------------------------------------------------
     def _gather_merge(self, Q, k, metric_id, exact):
@@ -118,6 +262,9 @@ class ShardedIndex:
         eng = self.engine
         nq = int(Q.shape[0])
         nb = eng.packed_bytes(nq, k)
+        if self._hx is not None and nb <= self._hx.slot_bytes:
+            mine = eng.topk_record_host(Q, k, metric_id, exact=exact)
+            return self._hx.exchange_merge(mine, nq, k)
         rec = eng.new_record(nb, 0)
         eng.topk_packed(Q, k, metric_id, rec, exact=exact)
         if self.world == 1 and not self.force_exchange:
@@ -137,7 +284,7 @@ class ShardedIndex:
         (MAX) of a scalar when the term is set -- nothing is exchanged per query.  `timestamps` = this shard's rows."""
         ts_max = self.engine.local_ts_max(timestamps)
         if self.world > 1:
-            t = torch.tensor([ts_max], dtype=torch.float64, device=self.engine.device)
+            t = torch.tensor([ts_max], dtype=torch.float64, device=self._coll_device())
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
             ts_max = float(t.item())
         self.engine.set_recency(timestamps, recency_bias, ts_max)

@@ -108,3 +108,38 @@ def test_host_helpers_match_reference_semantics():
     for m in ("dot_product", "cosine_similarity", "euclidean_metric", "manhattan_distance", "jaccard_similarity",
               "pearson_correlation", "hamming_distance"):
         ranking._validate_metric(m)          # every metric of the reference's dispatch table is accepted
+
+
+@pytest.mark.parametrize("parts,k,levels", [(8, 100, 7), (2, 5, 2), (5, 333, 50), (1, 64, 4)])
+def test_host_merge_ties_padding_and_interleaved_rows(parts, k, levels):
+    """hdb_merge_topk_host (host code of the library, no GPU) against numpy: heavy score ties across parts, row ids
+    interleaved between parts (tie order follows the row id, not the part), ragged lists padded with -1, status OR."""
+    import numpy as np
+    from hyperdb import _native
+    rng = np.random.default_rng(parts * 1000 + k)
+    nq = 3
+    nb = _native.packed_bytes(nq, k)
+    recs = np.zeros(parts * nb, dtype=np.uint8)
+    want_i = np.full((nq, k), -1, np.int64)
+    want_s = np.full((nq, k), -np.inf, np.float32)
+    want_st = np.zeros(nq, np.int32)
+    views = [_native.record_views(recs[p * nb:(p + 1) * nb], nq, k) for p in range(parts)]
+    for p in range(parts):
+        views[p][0][:], views[p][1][:] = -1, -np.inf
+    for q in range(nq):
+        rows = rng.permutation(parts * k * 2)[:parts * k].reshape(parts, k)
+        allp = []
+        for p in range(parts):
+            m = int(rng.integers(0, k + 1)) if q == 1 else k          # query 1: ragged lists
+            sc = rng.integers(0, levels, size=m).astype(np.float32)
+            order = np.lexsort((rows[p, :m], -sc))
+            views[p][0][q, :m], views[p][1][q, :m] = rows[p, :m][order], sc[order]
+            allp += list(zip(-sc, rows[p, :m]))
+            st = int(rng.integers(0, 2)) << int(rng.integers(0, 3))
+            views[p][2][q] = st
+            want_st[q] |= st
+        allp.sort()
+        for i, (ns, r) in enumerate(allp[:k]):
+            want_i[q, i], want_s[q, i] = r, -ns
+    gi, gs, gst = _native.merge_topk_host(recs, parts, nq, k, np.empty(nb, dtype=np.uint8))
+    assert np.array_equal(gi, want_i) and np.array_equal(gs, want_s) and np.array_equal(gst, want_st)

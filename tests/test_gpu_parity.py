@@ -463,8 +463,74 @@ def test_shard_merge_equals_global(orc):
         s.topk_packed(Q, k, mid, rec[p])
     pi, ps, pst = merge_topk_packed(rec, parts, 5, k)
     assert torch.equal(pi, gi) and torch.equal(ps, gs) and int(pst.abs().sum().item()) == 0
+    # the host flavour of the exchange: every shard's record in host memory, hdb_merge_topk_host
+    from hyperdb._native import merge_topk_host
+    host = np.concatenate([s.topk_record_host(Q, k, mid)[:nb].copy() for s in shards])
+    hi, hs, hst = merge_topk_host(host, parts, 5, k, np.empty(nb, dtype=np.uint8))
+    assert np.array_equal(hi, gi.cpu().numpy()) and np.array_equal(hs, gs.cpu().numpy()) and not hst.any()
     for s in shards + [whole]:
         s.close()
+
+
+def _two_rank_worker(rank, world, port, n, d, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "local-hyperdb_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # bookkeeping collectives on the host; both ranks share cuda:0
+    try:
+        import torch
+        import bench
+        from hyperdb._native import GpuIndex, METRIC_IDS
+        from hyperdb.sharded import ShardedIndex
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        V, lo, hi = bench.make_shard(n, d, torch.float16, rank, world, dev)
+        local = GpuIndex(V, device=dev, row_base=lo)
+        sh = ShardedIndex(local, n_total=n, group=dist.group.WORLD, exchange="host")
+        assert sh._hx is not None
+        Q = bench.make_queries(12, d, torch.float16, dev).float()
+        mid = METRIC_IDS["cosine_similarity"]
+        res = [sh.query(Q[i:i + 1], 100, mid) for i in range(10)]          # one exchange per query, slots reused
+        bi, bs = sh.query(Q[10:12], 37, mid)
+        sh.close()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), idx=np.stack([r[0][0] for r in res]), sc=np.stack([r[1][0] for r in res]), bi=bi, bs=bs)
+        local.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_host_exchange_equals_single_index(tmp_path):
+    """The launch model of bench.py with the product engine: two processes, each with its row shard in HBM (both on this
+    one GPU), swap their host records through the shared-memory exchange and merge with hdb_merge_topk_host -- every rank
+    gets exactly what one index over all rows returns."""
+    import torch
+    import torch.multiprocessing as mp
+    import bench
+    from hyperdb._native import GpuIndex, METRIC_IDS
+    n, d = 750_000, 384                                   # three 250k-row blocks: shards of 250k and 500k rows
+    port = 36500 + (os.getpid() % 2000)
+    mp.spawn(_two_rank_worker, args=(2, port, n, d, str(tmp_path)), nprocs=2, join=True)
+    dev = torch.device("cuda", 0)
+    V, _, _ = bench.make_shard(n, d, torch.float16, 0, 1, dev)
+    Q = bench.make_queries(12, d, torch.float16, dev).float()
+    whole = GpuIndex(V)
+    try:
+        mid = METRIC_IDS["cosine_similarity"]
+        r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+        for key in ("idx", "sc", "bi", "bs"):
+            assert np.array_equal(r0[key], r1[key]), key
+        for i in range(10):
+            wi, ws = whole.topk(Q[i:i + 1], 100, mid)
+            assert np.array_equal(r0["idx"][i], wi[0]) and np.array_equal(r0["sc"][i], ws[0]), i
+        wi, ws = whole.topk(Q[10:12], 37, mid)
+        assert np.array_equal(r0["bi"], wi) and np.array_equal(r0["bs"], ws)
+    finally:
+        whole.close()
 
 
 @pytest.mark.parametrize("parts,k,levels", [(8, 100, 7), (8, 1024, 3), (2, 5, 2), (5, 333, 50), (1, 64, 4)])

@@ -1,8 +1,9 @@
 """Row-sharded index over torch.distributed with the gloo backend, world_size 2 and 8, on CPU.
 
 What is under test is the HOST logic of hyperdb/sharded.py: shard bounds, the packed exchange record
-([idx int64 | score f32 | status i32]), ONE all-gather per batch, merge ordering, global row ids, and
-the collective exact re-run when any shard reports a failed threshold.  The compute engine is a
+([idx int64 | score f32 | status i32]), ONE exchange per batch -- the all-gather of device records AND the shared-memory
+swap of host records with the library's host merge (hdb_merge_topk_host: host code, runs here) --, merge ordering, global
+row ids, and the collective exact re-run when any shard reports a failed threshold.  The compute engine is a
 CPU stand-in defined HERE, in tests/, on top of the oracle -- the product engine (HipEngine) needs a
 GPU and is covered by tests/test_gpu_parity.py::test_shard_merge_equals_global.
 """
@@ -86,11 +87,17 @@ class OracleEngine:
     def record_to_host(self, record, nq, k):
         return self._views(record, nq, k)
 
+    # host-record flavour (HostExchange -> hdb_host_exchange_merge)
+    def topk_record_host(self, Q, k, metric_id, exact=False):
+        rec = self.new_record(self.packed_bytes(Q.shape[0], k))
+        self.topk_packed(Q, k, metric_id, rec, exact=exact)
+        return rec.numpy()
+
     def select_queries(self, Q, which):
         return Q[torch.as_tensor(which)]
 
 
-def _worker(rank, world, port, n, d, k, metric_id, fail_rank, out_dir, recency=False):
+def _worker(rank, world, port, n, d, k, metric_id, fail_rank, out_dir, recency=False, exchange="collective"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "local-hyperdb_amd"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -104,23 +111,29 @@ def _worker(rank, world, port, n, d, k, metric_id, fail_rank, out_dir, recency=F
         Q = torch.from_numpy(rng.standard_normal((4, d)).astype(np.float32))
         lo, hi = shard_bounds(n, world, granule=16)[rank]
         eng = OracleEngine(V[lo:hi], lo, fail_query=2 if rank == fail_rank else None)
-        sh = ShardedIndex(None, n_total=n, group=dist.group.WORLD, engine=eng)
+        sh = ShardedIndex(None, n_total=n, group=dist.group.WORLD, engine=eng, exchange=exchange)
+        assert (sh._hx is not None) == (exchange == "host")
         if recency:      # rows get newer with the row id: every shard has a different local maximum
             ts = 1.7e9 + np.arange(n, dtype=np.float64) * 0.002
             sh.set_recency(ts[lo:hi], 5.0)
         idx, sc = sh.query(Q, k, metric_id)
+        for rep in range(3):                              # later exchanges reuse the slots (two parities): same answer
+            i2, s2 = sh.query(Q, k, metric_id)
+            assert np.array_equal(i2, idx) and np.array_equal(s2, sc)
+        sh.close()
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), idx=idx, sc=sc, exact_calls=eng.exact_calls, lo=lo, hi=hi,
                  ts_max=(eng.ts_max_seen if eng.ts_max_seen is not None else np.nan))
     finally:
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("exchange", ["collective", "host"])
 @pytest.mark.parametrize("metric_id,fail_rank", [(1, None), (0, 1), (3, None)])
-def test_two_rank_gloo_matches_global(tmp_path, metric_id, fail_rank):
+def test_two_rank_gloo_matches_global(tmp_path, metric_id, fail_rank, exchange):
     from oracle import ranking_oracle as orc
     world, n, d, k = 2, 1000, 24, 10
-    port = 29500 + (os.getpid() % 2000) + metric_id
-    mp.spawn(_worker, args=(world, port, n, d, k, metric_id, fail_rank, str(tmp_path)), nprocs=world, join=True)
+    port = 29500 + (os.getpid() % 2000) + metric_id + (10 if exchange == "host" else 0)
+    mp.spawn(_worker, args=(world, port, n, d, k, metric_id, fail_rank, str(tmp_path), False, exchange), nprocs=world, join=True)
     rng = np.random.default_rng(77)
     V = rng.standard_normal((n, d)).astype(np.float32)
     V[n // 2 + 3] = V[5]
@@ -134,17 +147,18 @@ def test_two_rank_gloo_matches_global(tmp_path, metric_id, fail_rank):
         assert np.array_equal(r0["idx"][qi], want), (qi, r0["idx"][qi], want)
         assert np.array_equal(r0["sc"][qi], ex[want])
     # a failed threshold on ONE rank triggers the exact re-run on BOTH (collective consistency)
-    expect_exact = 1 if fail_rank is not None else 0
+    expect_exact = 4 if fail_rank is not None else 0        # (the worker asks four times)
     assert int(r0["exact_calls"]) == expect_exact and int(r1["exact_calls"]) == expect_exact
 
 
-def test_eight_rank_gloo_matches_global(tmp_path):
+@pytest.mark.parametrize("exchange", ["collective", "host"])
+def test_eight_rank_gloo_matches_global(tmp_path, exchange):
     """The node-sized case (8 ranks, uneven granule-aligned shards, a failed threshold on rank 5) on CPU."""
     from oracle import ranking_oracle as orc
     from hyperdb.sharded import shard_bounds
     world, n, d, k, metric_id, fail_rank = 8, 1000, 24, 10, 1, 5
-    port = 31500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(world, port, n, d, k, metric_id, fail_rank, str(tmp_path)), nprocs=world, join=True)
+    port = 31500 + (os.getpid() % 2000) + (10 if exchange == "host" else 0)
+    mp.spawn(_worker, args=(world, port, n, d, k, metric_id, fail_rank, str(tmp_path), False, exchange), nprocs=world, join=True)
     rng = np.random.default_rng(77)
     V = rng.standard_normal((n, d)).astype(np.float32)
     V[n // 2 + 3] = V[5]
@@ -153,7 +167,7 @@ def test_eight_rank_gloo_matches_global(tmp_path):
     assert [(int(r["lo"]), int(r["hi"])) for r in ranks] == shard_bounds(n, world, granule=16)
     for r in ranks[1:]:
         assert np.array_equal(r["idx"], ranks[0]["idx"]) and np.array_equal(r["sc"], ranks[0]["sc"]), "ranks must agree"
-        assert int(r["exact_calls"]) == 1                    # one rank's failed threshold -> every rank re-runs
+        assert int(r["exact_calls"]) == 4                    # one rank's failed threshold -> every rank re-runs (four calls)
     for qi in range(4):
         ex = orc.exact_scores(V, Q[qi], METRICS[metric_id]).astype(np.float32)
         want = np.lexsort((np.arange(n), -ex))[:k]
