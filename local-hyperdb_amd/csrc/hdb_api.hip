@@ -973,9 +973,9 @@ static void group_worker(hdb_group* g, int p) {
                           : hdb_topk(ix, g->qdev[p], g->nq, g->k, g->metric, d_idx, d_sc, d_st, st);
             if (rc != HDB_OK) msg = hdb_last_error();
         }
-        if (rc == HDB_OK) {
-            e = hipEventRecord(g->ev[p], st);
-            if (e != hipSuccess) { rc = HDB_ERR_HIP; msg = std::string("hdb_group: event: ") + hipGetErrorString(e); }
+        if (rc == HDB_OK) {              // the record is in the pinned gather buffer once this shard's stream has drained
+            e = hipStreamSynchronize(st);
+            if (e != hipSuccess) { rc = HDB_ERR_HIP; msg = std::string("hdb_group: synchronize: ") + hipGetErrorString(e); }
         }
         {
             std::lock_guard<std::mutex> lk(g->mu);
@@ -1058,14 +1058,11 @@ static int group_round(hdb_group* g, const void* host_Q, size_t q_bytes, int nq,
             for (int r = 0; r < g->parts; ++r) { (void)hipSetDevice(g->ix[r]->device); (void)hipStreamSynchronize(g->st[r]); }
             return fail(g->rc[p], "shard " + std::to_string(p) + ": " + g->err[p]);
         }
-    HIP_TRY(hipSetDevice(g->merge_dev));
-    for (int p = 0; p < g->parts; ++p) HIP_TRY(hipStreamWaitEvent(g->merge_st, g->ev[p], 0));
-    const int64_t stride = (int64_t)g->stride;
-    LAUNCH_TRY(hdb_launch_merge(g->gather, stride, g->gather + (int64_t)nq * k * 8, stride, g->gather + (int64_t)nq * k * 12, stride,
-                                g->parts, nq, (uint32_t)k, reinterpret_cast<int64_t*>(merged),
-                                reinterpret_cast<float*>(merged + (size_t)nq * k * 8),
-                                reinterpret_cast<int32_t*>(merged + (size_t)nq * k * 12), g->merge_st));
-    HIP_TRY(hipStreamSynchronize(g->merge_st));
+    // every shard's record sits in host memory (each worker drained its stream): merge on the host -- no merge launch, no
+    // second synchronisation
+    std::vector<const char*> recs((size_t)g->parts);
+    for (int p = 0; p < g->parts; ++p) recs[p] = g->gather + (size_t)p * g->stride;
+    merge_host_records(recs.data(), g->parts, nq, k, merged);
     return HDB_OK;
 }
 
