@@ -397,7 +397,7 @@ class GpuIndex:
             host = torch.empty(packed_bytes(nq, k), dtype=torch.uint8, pin_memory=True)
             h = host.numpy()
             slot = (host, ctypes.c_void_p(host.data_ptr()), h[:nq * k * 8].view(np.int64).reshape(nq, k),
-                    h[nq * k * 8:nq * k * 12].view(np.float32).reshape(nq, k), h[nq * k * 12:nq * k * 12 + nq * 4].view(np.int32))
+                    h[nq * k * 8:nq * k * 12].view(np.float32).reshape(nq, k), h[nq * k * 12:nq * k * 12 + nq * 4].view(np.int32), h)
             self._host_records[(nq, k)] = slot
             while len(self._host_records) > HOST_RECORD_SLOTS:
                 self._host_records.popitem(last=False)
@@ -412,7 +412,7 @@ class GpuIndex:
         qt = self._query_tensor(Q, batched=True)
         nq = int(qt.shape[0])
         self.topk_views(qt, k, metric_id)
-        return self._host_records[(nq, int(k))][0].numpy()
+        return self._host_records[(nq, int(k))][5]
 
     def topk(self, Q, k, metric_id):
         """Top-k of a query batch on the host: (int64 [nq,k], float32 [nq,k]) (copies)."""

@@ -103,6 +103,7 @@ class HostExchange:
         self._cobj = ctypes.c_char.from_buffer(self._mm)
         self._addr = ctypes.addressof(self._cobj)      # for hdb_host_exchange_merge
         self._out = {}                                # (nq, k) -> (uint8 array, its address, its views)
+        self._rec_addr = {}
         self._count = 0
 
     def exchange_merge(self, record, nq, k):
@@ -115,7 +116,12 @@ class HostExchange:
             out = np.empty(_native.packed_bytes(nq, k), dtype=np.uint8)
             slot = self._out[(nq, k)] = (out, out.ctypes.data, _native.record_views(out, nq, k))
         self._count += 1
-        _native.host_exchange_merge(self._addr, self._stride, self.world, self.rank, self._count, record.ctypes.data, nq, k,
+        addr = self._rec_addr.get(id(record))             # the records are long-lived pinned buffers: look their address up once
+        if addr is None:
+            if len(self._rec_addr) > 64:
+                self._rec_addr.clear()
+            addr = self._rec_addr[id(record)] = (record.ctypes.data, record)     # (keeps the array alive: ids are not reused)
+        _native.host_exchange_merge(self._addr, self._stride, self.world, self.rank, self._count, addr[0], nq, k,
                                     slot[1], self.timeout_s)
         return slot[2]
 

@@ -1425,6 +1425,19 @@ def test_single_launch_pipeline_threshold_minus_inf(dt, n, d, nq):
         ix.close()
 
 
+def test_fuzz_single_launch_against_exact():
+    """tools/fuzz_fused.py inside the suite: 1 500 random shapes the single-launch pipeline takes (1-4 queries fp16, 1-2
+    float32, k <= 128, bias, masks, duplicate rows, clusters around a query, 8 200 .. 2.5 M rows) -- a call that reports
+    status 0 must equal the on-device exact selection bit for bit (the run that found the two exchange bugs of round 2)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_fused.py"), "1500", "21", "240"], cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    tail = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-400:]
+    assert r.returncode == 0 and "0 mismatches" in tail, (r.stdout[-1500:], r.stderr[-500:])
+
+
 @pytest.mark.parametrize("dt,n,d", [(np.float32, 549_592, 128), (np.float16, 700_000, 384)])
 def test_single_launch_pipeline_cluster_in_a_sample_tile(dt, n, d):
     """300 near-copies of one row, queried with that row: when the cluster falls into a tile of the row sample the
