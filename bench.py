@@ -298,6 +298,11 @@ def main():
         except Exception:
             traffic = None
 
+    exchange_desc = ("none" if world == 1 else
+                     "shared-memory swap of the ranks' host records + host merge, once per query" if sharded._hx is not None
+                     else "1 RCCL all-gather of packed top-k per query + merge kernel")
+    sharded.close()
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, V, Q)
@@ -319,8 +324,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if args.dtype == "fp32" else "f16", "data": "synthetic",
             "config": {"workload": f"N={args.n} d={args.d} {args.dtype} Q=1 {args.metric} top-{args.k}, row-sharded x{world}",
-                       "rows_per_gpu": hi - lo, "accumulate": "f32", "exchange": "none" if world == 1 else ("shared-memory swap of the ranks' host records + host merge, once per query"
-                                                                   if sharded._hx is not None else "1 RCCL all-gather of packed top-k per query + merge kernel")},
+                       "rows_per_gpu": hi - lo, "accumulate": "f32", "exchange": exchange_desc},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": headline_kernel, "kernel_us": kern_s * 1e6,
@@ -331,7 +335,6 @@ def main():
         if extras:
             out["extra"] = extras
         print(json.dumps(out))
-    sharded.close()
     if dist:
         dist.destroy_process_group()
 
