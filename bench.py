@@ -16,6 +16,9 @@ query and merged on every rank: on one node through a shared-memory swap of the 
 (hyperdb/sharded.py HostExchange + hdb_merge_topk_host), records above 64 KiB (the Q=256 leg) and HDB_EXCHANGE=collective
 through ONE RCCL all-gather + the merge kernel.
 
+HDB_BENCH_REHEARSAL=1 rehearses the N > 1 control flow on ONE GPU (every rank on device 0, gloo for the bookkeeping
+collectives): it checks that the multi-rank path runs end to end; its timings mean nothing.
+
 One JSON line is printed by rank 0.  Besides the contract fields it carries
   roofline      -- dominant kernel (the pass over all of V) timed with HIP events on its launch
                    stream inside the timed region; algorithmic bytes = rows * d * sizeof(elem).
@@ -184,13 +187,18 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if os.environ.get("HDB_BENCH_REHEARSAL") == "1":     # control-flow rehearsal of the N > 1 path on ONE GPU: every rank on
+        local_rank = 0                                    # device 0, gloo for the bookkeeping collectives (timings meaningless)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1 or os.environ.get("HDB_FORCE_DIST") == "1":     # HDB_FORCE_DIST: exercise the RCCL path on one GPU
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=device)
+        if os.environ.get("HDB_BENCH_REHEARSAL") == "1":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from hyperdb._native import GpuIndex, METRIC_IDS
     from hyperdb.sharded import ShardedIndex
