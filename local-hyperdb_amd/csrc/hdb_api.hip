@@ -813,9 +813,10 @@ extern "C" int hdb_topk_host(hdb_index* ix, const void* dev_Q, int32_t nq, int32
     int64_t* d_idx = reinterpret_cast<int64_t*>(rec);
     float* d_sc = reinterpret_cast<float*>(rec + (size_t)nq * k * 8);
     int32_t* d_st = reinterpret_cast<int32_t*>(rec + (size_t)nq * k * 12);
-    // Single-launch pipeline writing into a pinned record: its status words are stored last, behind a system-scope
-    // release, so the host can poll them instead of waiting for the kernel's completion signal (end-of-kernel drain,
-    // cache write-back, signal, wake-up: ~5 us).  The stream stays ordered: the next launch queues behind the kernel.
+    // Pinned record: the status words are stored last (by the single-launch kernel's final workgroup, or by each query's
+    // finalize workgroup), behind a system-scope release, so the host can poll them instead of waiting for the completion
+    // signal of the last kernel (end-of-kernel drain, cache write-back, signal, wake-up: ~5-10 us).  The stream stays
+    // ordered: the next launch queues behind the kernels.
     constexpr int32_t SENTINEL = 0x7FFFFFFF;
     volatile int32_t* poll = reinterpret_cast<volatile int32_t*>(static_cast<char*>(host_record) + (size_t)nq * k * 12);
     if (direct && ix->host_poll) for (int q = 0; q < nq; ++q) poll[q] = SENTINEL;
@@ -823,7 +824,7 @@ extern "C" int hdb_topk_host(hdb_index* ix, const void* dev_Q, int32_t nq, int32
     if (rc) return rc;
     if (!direct) HIP_TRY(hipMemcpyAsync(host_record, rec, bytes, hipMemcpyDeviceToHost, st));
     bool polled = false;
-    if (direct && ix->host_poll && ix->st_fused) {
+    if (direct && ix->host_poll && (ix->st_fused || ix->st_path != 3)) {      // (the k > 2048 full sort writes its status words elsewhere)
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned spins = 0;; ++spins) {
             bool done = true;

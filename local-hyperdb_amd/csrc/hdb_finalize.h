@@ -156,12 +156,18 @@ __device__ __forceinline__ uint32_t hdb_finalize_body(unsigned long long* buf, c
         }
     }
     }
-    if (threadIdx.x == 0 && status) {
-        int32_t st = extra_status;
-        if (total > cap) st |= HDB_Q_OVERFLOW;
-        if (nc < kk) st |= HDB_Q_UNDERFLOW;
-        if (qnan_flag) st |= HDB_Q_NAN;
-        status[q] = st;
+    if (status) {
+        // The status word goes out LAST, behind every thread's result stores and a system-scope release: a host that polls it
+        // in a pinned record (hdb_topk_host) may read this query's results as soon as the word has left its sentinel value.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int32_t st = extra_status;
+            if (total > cap) st |= HDB_Q_OVERFLOW;
+            if (nc < kk) st |= HDB_Q_UNDERFLOW;
+            if (qnan_flag) st |= HDB_Q_NAN;
+            __hip_atomic_store(status + q, st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     uint32_t kth_above = 0;
     if (floor_ptr) { __syncthreads(); kth_above = ctl[8]; }
