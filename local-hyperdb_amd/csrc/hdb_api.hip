@@ -523,7 +523,10 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     // 1-4 dot / cosine queries, k <= 128: one launch does everything (hdb_mfma_fused.h; fp16 on the matrix cores,
     // float32 in the VALU from the same staged tiles)
     const bool fused_shape = ix->use_fused && !exact && !small && k <= HDB_MAX_K && dev_status != nullptr && !is_ham && !is_pearson &&
-                             hdb_mfma_fused_supported(ix->dtype, ix->d, metric, nq, kk) && (ix->dtype == HDB_F32 || mfma);
+                             hdb_mfma_fused_supported(ix->dtype, ix->d, metric, nq, kk) && (ix->dtype == HDB_F32 || mfma) &&
+                             // float32 d = 512 streams 32-KiB tiles (16 rows): below ~3 GB the five-kernel VALU pipeline is
+                             // 2-5 % faster end to end (200 vs 210 us at 0.5 M rows, 376 vs 385 at 1 M; 728 vs 687 at 2 M)
+                             !(ix->dtype == HDB_F32 && ix->d == 512 && n < 1500000);
     const int tile_rows = (mfma || fused_shape) ? hdb_mfma_tile_rows(ix->dtype, ix->d) : 16;
 
     // ---- plan the chunking --------------------------------------------------------------------

@@ -103,7 +103,8 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     constexpr int ROWB = D * (int)sizeof(E);
     constexpr int NJ = ROWB / 256;              // VALU: 16-byte chunks per lane and row (16 lanes cover a row)
     constexpr int NP = R / 16;                  // VALU: 16-row passes per tile ...
-    constexpr int NPW = NP / 2;                 // ... per computing wave (two of them)
+    constexpr bool TWOCW = NP >= 2;             // two computing waves (0 and 2) share the passes; 16-row tiles have one pass: wave 0 alone
+    constexpr int NPW = TWOCW ? NP / 2 : 1;     // ... per computing wave
     // VQ (VALU flavour only): queries per call, 1 or 2 -- their chunks live in registers (VQ x D/16 of them), and a
     // single query must not pay for a second one
     constexpr int CPR = ROWB / 16;
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     constexpr int NLOADB = NGL + (AUX0 ? 1 : 0) + (HAS_BIAS ? 1 : 0);
     constexpr int M = HDB_FUSED_M;
     static_assert(R % MF == 0 && R <= 64 && (R * CPR) % 512 == 0 && ROWB % 256 == 0, "tile geometry");
-    static_assert(!VALU || (NJ * VQ <= 12 && NP % 2 == 0), "float32 flavour: query chunks in registers, two computing waves");
+    static_assert(!VALU || (NJ * VQ <= 12 && (NP % 2 == 0 || NP == 1)), "float32 flavour: query chunks in registers, one or two computing waves");
     static_assert(METRIC == 0 || METRIC == 1, "dot / cosine");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -150,8 +151,8 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     const int lw = w & 3;
     // fp16: wave 0 multiplies (nq <= 16: the kernel is a streaming kernel); wave 1: selector of queries 0-1, wave 2: of 2-3.
     // float32: waves 0 and 2 compute (even / odd 16-row passes of a tile), wave 1 is the selector of both queries.
-    const bool mfma_wave = w == 0 || (VALU && w == 2);
-    const int pp0 = VALU ? (w >> 1) : 0;            // first pass of this computing wave
+    const bool mfma_wave = w == 0 || (VALU && TWOCW && w == 2);
+    const int pp0 = VALU && TWOCW ? (w >> 1) : 0;   // first pass of this computing wave
     const bool selector = (w == 1 || (w == 2 && !VALU)) && 2 * (w - 1) < nq;
     const bool requester = w == 3;
     const int64_t G = gridDim.x;
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
         const int u_own = hdb_owned_row(l16);
 #pragma unroll
         for (int k2 = 0; k2 < (VALU ? NPW : 1); ++k2) {
-            const int pp = 2 * k2 + pp0;
+            const int pp = (TWOCW ? 2 : 1) * k2 + pp0;
             const int64_t row = row0 + 16 * pp + 4 * g4 + u_own;
 #pragma unroll
             for (int q = 0; q < VQ; ++q) {
@@ -710,7 +711,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
 #pragma unroll
                         for (int k2 = 0; k2 < NPW; ++k2)
                             if (q < nq && (l16 & 3) == 0)
-                                hdb_lds_st32(pbuf_addr + (unsigned int)((npend * VQ + q) * R + 16 * (2 * k2 + pp0) + 4 * g4 + u_own_p) * 4u, pend[k2][q]);
+                                hdb_lds_st32(pbuf_addr + (unsigned int)((npend * VQ + q) * R + 16 * ((TWOCW ? 2 : 1) * k2 + pp0) + 4 * g4 + u_own_p) * 4u, pend[k2][q]);
                     if (w == 0) park_row0(npend, row0_prev);
                     ++npend;
                 } else {
@@ -721,7 +722,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                         for (int q = 0; q < VQ; ++q)
 #pragma unroll
                             for (int k2 = 0; k2 < NPW; ++k2)
-                                tv[k2][q] = q < nq ? hdb_lds_ld32(pbuf_addr + (unsigned int)((p * VQ + q) * R + 16 * (2 * k2 + pp0) + 4 * g4 + u_own_p) * 4u) : -INFINITY;
+                                tv[k2][q] = q < nq ? hdb_lds_ld32(pbuf_addr + (unsigned int)((p * VQ + q) * R + 16 * ((TWOCW ? 2 : 1) * k2 + pp0) + 4 * g4 + u_own_p) * 4u) : -INFINITY;
                         filter_valu(tv, parked_row0(p));
                     }
                     npend = 0;
@@ -737,7 +738,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                 const int u_own = hdb_owned_row(l16);
 #pragma unroll
                 for (int k2 = 0; k2 < NPW; ++k2) {
-                    const int pp = 2 * k2 + pp0;
+                    const int pp = (TWOCW ? 2 : 1) * k2 + pp0;
                     // rows 16 pp + 4 g4 + u (u = 0..3); chunk c of row r sits at ((c ^ (r & 15)) << 4) of its row image
                     float accv[4][VQ];
 #pragma unroll
@@ -786,7 +787,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                             if (q < nq) {
                                 const unsigned int dst = tsc_addr + (unsigned int)(((int)(i & 1) * HDB_FUSED_MAXQ + q) * 64) * 4u;
 #pragma unroll
-                                for (int k2 = 0; k2 < NPW; ++k2) hdb_lds_st32(dst + (unsigned int)(16 * (2 * k2 + pp0) + 4 * g4 + u_own) * 4u, pend[k2][q]);
+                                for (int k2 = 0; k2 < NPW; ++k2) hdb_lds_st32(dst + (unsigned int)(16 * ((TWOCW ? 2 : 1) * k2 + pp0) + 4 * g4 + u_own) * 4u, pend[k2][q]);
                             }
                         }
                     }

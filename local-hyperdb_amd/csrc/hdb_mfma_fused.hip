@@ -7,8 +7,10 @@ extern "C" int hdb_mfma_tile_rows(int dtype, int d);
 extern "C" int hdb_mfma_fused_supported(int dtype, int d, int metric, int nq, uint32_t kk) {
     // d <= 768: beyond that the query fragments (d/8 registers) leave no room for the selectors' state without spilling
     const bool shape = (dtype == HDB_F16 && hdb_mfma_tile_rows(dtype, d) > 0 && d <= 768) ||
-                       (dtype == HDB_F32 && (d == 128 || d == 256 || d == 384));      // float32: VALU flavour, up to 2 queries (48 query registers at d = 384)
-    return shape && (metric == HDB_DOT || metric == HDB_COSINE) && nq >= 1 && nq <= (dtype == HDB_F32 ? 2 : HDB_FUSED_MAXQ) && kk <= 128;
+                       (dtype == HDB_F32 && (d == 128 || d == 256 || d == 384 || d == 512 || d == 768));   // float32: VALU flavour
+    // float32 queries live in registers as d/4 floats per lane group: 48 registers = 2 queries up to d = 384, 1 beyond
+    const int maxq = dtype == HDB_F32 ? (d <= 384 ? 2 : 1) : HDB_FUSED_MAXQ;
+    return shape && (metric == HDB_DOT || metric == HDB_COSINE) && nq >= 1 && nq <= maxq && kk <= 128;
 }
 
 // bytes of the persistent control block: 64 words of counters + the granules
@@ -29,6 +31,8 @@ extern "C" int hdb_launch_mfma_fused(const ScanArgs* args, int dtype, const Fuse
             case 128: return f.nq == 1 ? launch_fused<float, 1, 128, 64>(a, f, blocks, st) : launch_fused<float, 2, 128, 64>(a, f, blocks, st);
             case 256: return f.nq == 1 ? launch_fused<float, 1, 256, 32>(a, f, blocks, st) : launch_fused<float, 2, 256, 32>(a, f, blocks, st);
             case 384: return f.nq == 1 ? launch_fused<float, 1, 384, 32>(a, f, blocks, st) : launch_fused<float, 2, 384, 32>(a, f, blocks, st);
+            case 512: return launch_fused<float, 1, 512, 16>(a, f, blocks, st);
+            case 768: return launch_fused<float, 1, 768, 16>(a, f, blocks, st);
             default: return (int)hipErrorNotSupported;
         }
     }

@@ -21,3 +21,19 @@ for dt, es in ((torch.float32, 4), (torch.float16, 2)):
         t = min(ts)
         print(f"{'fp32' if es == 4 else 'fp16'} n={n}: kernel {t:.1f} us, {n*384*es/t/1e3:.0f} GB/s, fused={ix.stat('fused')}", flush=True)
         ix.close(); del V; torch.cuda.empty_cache()
+for d in (512, 768):
+    for n in (500_000, 1_000_000, 2_000_000):
+        V, lo, hi = bench.make_shard(n, d, torch.float32, 0, 1, dev)
+        ix = GpuIndex(V)
+        Q = bench.make_queries(8, d, torch.float32, dev)
+        res = {}
+        for fused in (1, 0):
+            ix.set_option('use_fused', fused)
+            for i in range(5): ix.topk_views(Q[i % 8:i % 8 + 1], 100, mid)
+            import time, numpy as np
+            lat = []
+            for i in range(100):
+                t0 = time.perf_counter(); ix.topk_views(Q[i % 8:i % 8 + 1], 100, mid); lat.append(time.perf_counter() - t0)
+            res[fused] = float(np.median(lat)) * 1e6
+        print(f"fp32 d={d} n={n}: host call p50 single launch {res[1]:.1f} us, five kernels {res[0]:.1f} us, {n*d*4/res[1]/1e3:.0f} GB/s end to end", flush=True)
+        ix.close(); del V; torch.cuda.empty_cache()
