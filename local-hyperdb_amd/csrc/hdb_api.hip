@@ -526,7 +526,10 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
                              hdb_mfma_fused_supported(ix->dtype, ix->d, metric, nq, kk) && (ix->dtype == HDB_F32 || mfma) &&
                              // float32 d = 512 streams 32-KiB tiles (16 rows): below ~3 GB the five-kernel VALU pipeline is
                              // 2-5 % faster end to end (200 vs 210 us at 0.5 M rows, 376 vs 385 at 1 M; 728 vs 687 at 2 M)
-                             !(ix->dtype == HDB_F32 && ix->d == 512 && n < 1500000);
+                             !(ix->dtype == HDB_F32 && ix->d == 512 && n < 1500000) &&
+                             // fp16 d = 1024 (32-KiB tiles, 32 k-steps in one wave): 189 vs 195 us at 0.5 M rows, 619 vs 627 at 2 M,
+                             // but 1 491 vs 1 466 at 5 M -- the single launch up to 4 M rows
+                             !(ix->dtype == HDB_F16 && ix->d == 1024 && n > 4000000);
     const int tile_rows = (mfma || fused_shape) ? hdb_mfma_tile_rows(ix->dtype, ix->d) : 16;
 
     // ---- plan the chunking --------------------------------------------------------------------

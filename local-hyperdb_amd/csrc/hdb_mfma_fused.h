@@ -6,7 +6,7 @@
 //
 // Roles of the eight waves (a wave that blocks on an exchange must not also be on the staging path):
 //   wave 0 multiplies and filters; waves 1-2 are the selectors (two queries each); wave 3 requests tile chunks from the
-//   global counter; waves 4-7 stage the tiles (LDS-DMA, 2*NG pieces of 1 KiB each per tile) and the per-row aux values.
+//   global counter; waves 4-7 stage the tiles (LDS-DMA, pieces of 1 KiB each) and the per-row aux values.
 // Structure (persistent, one 512-thread workgroup per CU, the LDS ring of hdb_mfma_kernel.h):
 //   prologue  every workgroup converts the float32 queries itself (fp16 copies scaled by a power of two into LDS,
 //             1/||q||, NaN flag): 4 x d elements, cheaper than a launch.
@@ -112,13 +112,17 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     constexpr int KS = CPR / CPS;
     constexpr int RT = R / MF;
     constexpr int STAGE = R * ROWB;
-    constexpr int NG = R * CPR / 64 / 8;
+    // BLDS: beyond d = 768 the query fragments (d/8 registers) do not fit beside the selectors' state: they stay in LDS (up
+    // to 2 queries, inside the candidate-list region, which then keeps 256 entries) and wave 0 reads one fragment per k-step
+    constexpr bool BLDS = !VALU && D > 768;
+    constexpr int CB = BLDS ? 256 : HDB_MFMA_CB;   // LDS candidate-list entries in use
     constexpr bool AUX0 = METRIC != 0;
-    constexpr int NGL = 2 * NG;                 // pieces per staging wave and tile (waves 4-7)
+    constexpr int NGL = R * CPR / 256;          // pieces per staging wave and tile (waves 4-7)
     constexpr int NLOADA = NGL;
     constexpr int NLOADB = NGL + (AUX0 ? 1 : 0) + (HAS_BIAS ? 1 : 0);
     constexpr int M = HDB_FUSED_M;
-    static_assert(R % MF == 0 && R <= 64 && (R * CPR) % 512 == 0 && ROWB % 256 == 0, "tile geometry");
+    static_assert(R % MF == 0 && R <= 64 && (R * CPR) % 256 == 0 && ROWB % 256 == 0, "tile geometry");
+    static_assert(!BLDS || (RT == 1 && 2 * D * 2 + 2048 <= HDB_MFMA_CB * 8), "LDS-resident fragments: 16-row tiles, two queries behind 2 KiB of list");
     static_assert(!VALU || (NJ * VQ <= 12 && (NP % 2 == 0 || NP == 1)), "float32 flavour: query chunks in registers, one or two computing waves");
     static_assert(METRIC == 0 || METRIC == 1, "dot / cosine");
 
@@ -129,14 +133,16 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     unsigned int* ctl = reinterpret_cast<unsigned int*>(cbq + HDB_MFMA_CB);       // [0] count, [1..2] flush flags, [3] last-workgroup flag
     float* tsc = reinterpret_cast<float*>(ctl + 16);                               // [2][MAXQ][64] scores of the latest sample tiles
     float* qpar = tsc + 2 * HDB_FUSED_MAXQ * 64;                                   // [MAXQ] multiplier, [MAXQ] NaN flag, [MAXQ] threshold
-    char* qlds = smem + 2 * STAGE;                                                // prologue scratch: [nq][D] queries in E (ring slot 2, not yet in use)
+    // [nq][D] queries in E: prologue scratch in ring slot 2 (not yet in use) -- or, BLDS, resident behind the first 2 KiB of the list
+    char* qlds = BLDS ? reinterpret_cast<char*>(cb) + 2048 : smem + 2 * STAGE;
     // Parked scores (see "parking" in the tile loop): [HDB_FUSED_PEND] tiles x [queries] x [rows] floats.  The MFMA flavour
     // (4 queries x 64 rows = 1 KiB per tile) parks in the candidate list, which is empty until a threshold exists; the
     // float32 flavour (VQ queries x R rows) has an area of its own behind qpar.  tsc is free once the sample tiles are
     // merged and holds the first row of each parked tile.
     float* pbuf = VALU ? qpar + 16 : reinterpret_cast<float*>(cb);
     static_assert(HDB_FUSED_PEND * HDB_FUSED_MAXQ * 64 * 4 <= HDB_MFMA_CB * 8, "parked MFMA scores live in the candidate list");
-    constexpr bool PARK = VALU || D <= 640;       // d = 768 would spill with it: there the selector holds the round as before
+    static_assert(!BLDS || 16 * 2 * R * 4 <= 2048, "parked scores of 16 tiles x 2 queries fit the first 2 KiB");
+    constexpr bool PARK = VALU || D <= 640 || BLDS;       // d = 768 would spill with it: there the selector holds the round as before
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -145,7 +151,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     const int nq = f.nq;
     // parked tiles: the MFMA flavour packs nq x 64 floats per tile into the 8 KiB list, the float32 flavour VQ x R floats into its area
     const int pend_max = VALU ? 2 * HDB_FUSED_PEND / VQ : (nq <= 2 ? 16 : 32 / nq);
-    const unsigned int pend_stride = (unsigned int)nq * 256u;      // MFMA flavour: bytes per parked tile
+    const unsigned int pend_stride = (unsigned int)(nq * R * 4);   // MFMA flavour: bytes per parked tile
     const bool loader = w >= 4;                     // waves 4-7 stage the tiles
     const bool grpB = w >= 6;                       // ... 6-7 also the per-row aux values
     const int lw = w & 3;
@@ -175,11 +181,14 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     // answers over through LDS.
     // The counter is one address: it answers ~70 requests per us, and G workgroups asking for ONE tile per 1.6-us round
     // (160 / us) queue up behind it -- 3 us per tile instead of 1.7 (N = 500k: 109 us for 31 tiles per workgroup).  So
-    // requests are always for 4 tiles (2 at the very end), matrices of 8..32 tiles per workgroup take the first half of
+    // requests are always for CHL tiles (half at the very end), matrices of 2..8 requests per workgroup take the first half of
     // their chunks statically, and smaller ones are split statically altogether.
     const int64_t ntiles = a.ntiles;
-    const int64_t CH = ntiles >= 8 * G ? 4 : 1;      // size of the fixed chunks (and of the large requests)
-    const int64_t S = ntiles >= 32 * G ? 1 : ntiles >= 8 * G ? ntiles / (8 * G) : (ntiles + G - 1) / G;
+    // A request covers ~192 KiB of V (4 tiles of 48 KiB, 6 of 32, 12 of 16): tiles of 28-40 KiB stream in 1.0-1.4 us, and four
+    // of them per request put G / (4 x 1.1 us) = 58 requests per us on the counter (d=1024: 1.53 us per tile instead of 1.15).
+    constexpr int64_t CHL = (4 * 48 * 1024 + STAGE - 1) / STAGE;
+    const int64_t CH = ntiles >= 2 * CHL * G ? CHL : 1;      // size of the fixed chunks (and of the large requests)
+    const int64_t S = ntiles >= 8 * CHL * G ? 1 : ntiles >= 2 * CHL * G ? ntiles / (2 * CHL * G) : (ntiles + G - 1) / G;
     const int64_t dyn0 = S * G * CH;                 // first tile handed out by the counter
     unsigned int* dq = ctl + 4;                      // [2][2] {first tile - dyn0, length} handed over by wave 7
     const unsigned int dq_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(dq);
@@ -203,9 +212,9 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
             // Request the chunk after this one two rounds before its first tile is generated (the counter answers within a
             // round): a workgroup then never holds more than the chunk it works on, which bounds the finishing skew.
             if (requester && coff == (clen >= 2 ? clen - 2 : 0) && cidx + 1 >= S) {
-                // 4 tiles per request while plenty are left, 2 for the last ~6 rounds of the grid: the slowest workgroups
+                // CH tiles per request while plenty are left, half of that for the last rounds of the grid: the slowest workgroups
                 // stream ~25 % slower than the fastest, and what they still hold when the counter runs dry is the tail
-                const unsigned int want = CH == 1 ? 1u : (ntiles - dyn0 - seen > 6 * G ? (unsigned int)CH : 2u);
+                const unsigned int want = CH == 1 ? 1u : (ntiles - dyn0 - seen > (CH + CH / 2) * G ? (unsigned int)CH : (unsigned int)(CH / 2));
                 unsigned int got = 0u;
                 if (lane == 0) got = __hip_atomic_fetch_add(f.ctl + 32, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 got = (unsigned int)__builtin_amdgcn_readfirstlane((int)got);
@@ -297,7 +306,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
 
     // ---- wave 0: B fragments and per-query constants ---------------------------------------------
     const bool q_ok = rl < nq;
-    Vec Bq[VALU ? 1 : KS];
+    Vec Bq[(VALU || BLDS) ? 1 : KS];
     float qinv_l = 1.f;
     // VALU flavour: lane (group g = lane >> 4, l16 = lane & 15) holds chunks l16 + 16 j of every query, and the per-query
     // multipliers / thresholds as wave-uniform values
@@ -318,6 +327,8 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                 }
                 if (q < nq) qmul[q] = hdb_lds_ld32(qpar_addr + (unsigned int)q * 4u);
             }
+        } else if constexpr (BLDS) {
+            if (q_ok) qinv_l = hdb_lds_ld32(qpar_addr + (unsigned int)rl * 4u);
         } else {
             const unsigned int src = qlds_addr + (unsigned int)((q_ok ? rl : 0) * D) * 2u + (unsigned int)h * 16u;
 #pragma unroll
@@ -349,12 +360,12 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     // up by 20 us.
     auto flush = [&]() {
         hdb_lds_barrier();
-        const unsigned int ne = ctl[0] < HDB_MFMA_CB ? ctl[0] : HDB_MFMA_CB;
+        const unsigned int ne = ctl[0] < CB ? ctl[0] : CB;
         if (tid < 8) ctl[8 + tid] = 0;               // [8..11] entries per query, [12..15] their first global slot
         hdb_lds_barrier();
-        unsigned int rank[HDB_MFMA_CB / 512];
+        unsigned int rank[(CB + 511) / 512];
 #pragma unroll
-        for (int u = 0; u < HDB_MFMA_CB / 512; ++u) {
+        for (int u = 0; u < (CB + 511) / 512; ++u) {
             const unsigned int e = tid + 512 * u;
             rank[u] = e < ne ? atomicAdd(&ctl[8 + cbq[e]], 1u) : 0u;
         }
@@ -365,7 +376,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
         }
         hdb_lds_barrier();
 #pragma unroll
-        for (int u = 0; u < HDB_MFMA_CB / 512; ++u) {
+        for (int u = 0; u < (CB + 511) / 512; ++u) {
             const unsigned int e = tid + 512 * u;
             if (e < ne) {
                 const unsigned int qe = cbq[e];
@@ -397,12 +408,12 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float x = tv[rt][j];
-                        if (x >= thr_cmp && rowg + j < n_rows && !(HAS_BIAS && x == -INFINITY)) {
+                        if (x >= thr_cmp && q_ok && rowg + j < n_rows && !(HAS_BIAS && x == -INFINITY)) {
                             const float sc = hdb_canon(HAS_BIAS ? x : x * qinv_l);
-                            unsigned int pos = HDB_MFMA_CB;
+                            unsigned int pos = CB;
                             if (!(PARK && direct)) asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
                                                       : "=&v"(pos) : "v"(ctl_addr), "v"(1u) : "memory");
-                            if (pos < HDB_MFMA_CB) {
+                            if (pos < CB) {
                                 const unsigned long long ent = hdb_pack(sc, (uint32_t)(rowg + j));
                                 asm volatile("ds_write_b64 %0, %1\n\tds_write_b16 %2, %3"
                                              :: "v"(cb_addr + pos * 8u), "v"(ent), "v"(cbq_addr + pos * 2u), "v"((unsigned int)rl) : "memory");
@@ -433,7 +444,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                     unsigned int pos;
                     asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pos) : "v"(ctl_addr), "v"(1u) : "memory");
                     const unsigned long long ent = hdb_pack(sc, (uint32_t)row);
-                    if (pos < HDB_MFMA_CB) {
+                    if (pos < CB) {
                         asm volatile("ds_write_b64 %0, %1\n\tds_write_b16 %2, %3"
                                      :: "v"(cb_addr + pos * 8u), "v"(ent), "v"(cbq_addr + pos * 2u), "v"((unsigned int)q) : "memory");
                     } else {
@@ -503,7 +514,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
         }
         const bool chk = tile && i >= nA && ((i - nA) & chk_mask) == chk_mask;
         const int chk_slot = 1 + (int)(((i - nA) >> chk_shift) & 1);
-        if (chk && tid == 0) ctl[chk_slot] = (ctl[0] >= HDB_MFMA_CB / 4) ? 1u : 0u;
+        if (chk && tid == 0) ctl[chk_slot] = (ctl[0] >= CB / 4) ? 1u : 0u;
         hdb_lds_barrier();                           // tile i is in LDS; everyone is done with tile i-1; tsc/qpar/dq hand-offs
         const int st_next2 = st_cur == 0 ? 2 : st_cur - 1;
         if (vB) gen(rC, vC); else vC = false;        // positions past the end are never generated (no stray requests)
@@ -816,7 +827,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                         --thr_reads;
                     }
                 }
-                const unsigned int pslot = (unsigned int)(rl * 64 + 4 * h) * 4u;
+                const unsigned int pslot = (unsigned int)(rl * R + 4 * h) * 4u;
                 if (PARK && !thr_known) {            // parking: keep the comparable values of this tile, filter them later
                     if (q_ok) {
 #pragma unroll
@@ -875,6 +886,37 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                 for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[rt][e] = 0.f;
+                if constexpr (BLDS) {
+                    // query fragments from LDS, one read per k-step next to the row fragment (RT == 1): two LDS reads per step,
+                    // PFB steps in flight (lgkmcnt counts to 15: 7 steps at most) -- with 3 steps the LDS latency under staging
+                    // traffic was exposed at every step); lanes of columns without a query read query 0's fragment
+                    constexpr int PFB = 7;
+                    const unsigned int bsrc = qlds_addr + (unsigned int)((q_ok ? rl : 0) * D) * 2u + (unsigned int)h * 16u;
+                    Vec abl[PFB + 1], bbl[PFB + 1];
+                    auto fetch_ab = [&](int s, Vec& da, Vec& db) {
+                        const unsigned int ad = sb_addr + ((unsigned int)(16 * CPS * s) ^ hx);
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(da) : "v"(ad));
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(db) : "v"(bsrc), "i"(CPS * 16 * (s < KS ? s : 0)));
+                    };
+#pragma unroll
+                    for (int s = 0; s < PFB && s < KS; ++s) fetch_ab(s, abl[s % (PFB + 1)], bbl[s % (PFB + 1)]);
+#pragma unroll
+                    for (int s = 0; s < KS; ++s) {
+                        if (s + PFB < KS) fetch_ab(s + PFB, abl[(s + PFB) % (PFB + 1)], bbl[(s + PFB) % (PFB + 1)]);
+                        const int pend = (KS - 1 - s) < PFB ? (KS - 1 - s) : PFB;      // steps still in flight behind step s: 2 reads each
+                        Vec& af = abl[s % (PFB + 1)];
+                        Vec& bf = bbl[s % (PFB + 1)];
+                        if (pend == 7) asm volatile("s_waitcnt lgkmcnt(14)" : "+v"(af), "+v"(bf));
+                        else if (pend == 6) asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(af), "+v"(bf));
+                        else if (pend == 5) asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(af), "+v"(bf));
+                        else if (pend == 4) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(af), "+v"(bf));
+                        else if (pend == 3) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(af), "+v"(bf));
+                        else if (pend == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(af), "+v"(bf));
+                        else if (pend == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(af), "+v"(bf));
+                        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af), "+v"(bf));
+                        acc[0] = Shape::mma(af, bf, acc[0]);     // columns without a query repeat query 0 and are never looked at
+                    }
+                } else {
 #pragma unroll
                 for (int s = 0; s < PF && s < KS; ++s) fetch(s, abuf[s % (PF + 1)]);
 #pragma unroll
@@ -884,6 +926,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                     wait_frag(pend, abuf[s % (PF + 1)]);
 #pragma unroll
                     for (int rt = 0; rt < RT; ++rt) acc[rt] = Shape::mma(abuf[s % (PF + 1)][rt], Bq[s], acc[rt]);
+                }
                 }
                 // comparable values, in place
                 if (METRIC != 0 || HAS_BIAS) {

@@ -3,13 +3,16 @@
 #include "hdb_mfma_fused.h"
 
 extern "C" int hdb_mfma_tile_rows(int dtype, int d);
+extern "C" int hdb_launch_mfma_fused_wide(const ScanArgs* args, const FusedArgs* f, int blocks, void* stream);
 
 extern "C" int hdb_mfma_fused_supported(int dtype, int d, int metric, int nq, uint32_t kk) {
-    // d <= 768: beyond that the query fragments (d/8 registers) leave no room for the selectors' state without spilling
-    const bool shape = (dtype == HDB_F16 && hdb_mfma_tile_rows(dtype, d) > 0 && d <= 768) ||
+    // fp16: every width the batched scan takes (multiples of 128 up to 1536); beyond d = 768 the query fragments (d/8
+    // registers) leave no room for the selectors' state: they stay in LDS, up to 2 queries (hdb_mfma_fused_wide.hip)
+    // (d = 896: 28-KiB tiles of 28 k-steps keep the one multiplying wave busier than the stream: five kernels are 6 % faster)
+    const bool shape = (dtype == HDB_F16 && hdb_mfma_tile_rows(dtype, d) > 0 && d % 128 == 0 && d != 896) ||
                        (dtype == HDB_F32 && (d == 128 || d == 256 || d == 384 || d == 512 || d == 768));   // float32: VALU flavour
     // float32 queries live in registers as d/4 floats per lane group: 48 registers = 2 queries up to d = 384, 1 beyond
-    const int maxq = dtype == HDB_F32 ? (d <= 384 ? 2 : 1) : HDB_FUSED_MAXQ;
+    const int maxq = dtype == HDB_F32 ? (d <= 384 ? 2 : 1) : (d <= 768 ? HDB_FUSED_MAXQ : 2);
     return shape && (metric == HDB_DOT || metric == HDB_COSINE) && nq >= 1 && nq <= maxq && kk <= 128;
 }
 
@@ -43,7 +46,7 @@ extern "C" int hdb_launch_mfma_fused(const ScanArgs* args, int dtype, const Fuse
         case 512: return launch_fused<_Float16, 2, 512, 32>(a, f, blocks, st);
         case 640: return launch_fused<_Float16, 2, 640, 32>(a, f, blocks, st);
         case 768: return launch_fused<_Float16, 2, 768, 32>(a, f, blocks, st);
-        default: return (int)hipErrorNotSupported;
+        default: return hdb_launch_mfma_fused_wide(&a, &f, blocks, stream);
     }
 }
 
