@@ -207,3 +207,44 @@ def test_shard_bounds_cover_everything():
         assert b[0][0] == 0 and b[-1][1] == n
         assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
         assert all(lo % g == 0 for lo, _ in b)
+
+
+def _timeout_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "local-hyperdb_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hyperdb.sharded import HostExchange
+        from hyperdb import _native
+        hx = HostExchange(dist.group.WORLD, rank, world, torch.device("cpu"), timeout_s=1.0)
+        nq, k = 2, 5
+        rec = np.zeros(_native.packed_bytes(nq, k), dtype=np.uint8)
+        idx, sc, st = _native.record_views(rec, nq, k)
+        idx[:], sc[:] = rank * 100 + np.arange(k), -np.arange(k, dtype=np.float32) - rank * 0.5
+        i1, s1, _ = hx.exchange_merge(rec, nq, k)                       # a normal exchange first
+        ok = bool(np.array_equal(i1[0], [0, 100, 1, 101, 2]))
+        err = ""
+        if rank == 0:
+            try:
+                hx.exchange_merge(rec, nq, k)                           # rank 1 never comes
+            except RuntimeError as e:
+                err = str(e)
+        with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+            f.write(f"{int(ok)}|{err}")
+        dist.barrier()
+        hx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_host_exchange_times_out_when_a_rank_does_not_publish(tmp_path):
+    """The shared-memory swap merges what both ranks published; a rank that waits for a record that never comes gets a
+    RuntimeError after its timeout instead of spinning for ever."""
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_timeout_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = open(tmp_path / "rank0.txt").read().split("|")
+    r1 = open(tmp_path / "rank1.txt").read().split("|")
+    assert r0[0] == "1" and r1[0] == "1"
+    assert "did not publish" in r0[1] and r1[1] == ""
