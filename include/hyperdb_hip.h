@@ -136,7 +136,7 @@ int hdb_scores(hdb_index* ix, const void* dev_q, int metric, float* dev_out, voi
  * float32 query is rounded to 11 significant bits per element (score error ~1e-4 relative, inside the 1e-3
  * contract for fp16 data).  hdb_set_option(ix, "use_mfma", 0) keeps float32 queries unrounded (VALU scan).
  * float32 matrices (d in {128,256,384,512,768}) take batches of 5+ queries through fp32 MFMAs: exact fp32 products.
- * Calls of 1-4 dot / cosine queries with k <= 128 on an fp16 matrix (d <= 768; 1-2 queries for d = 1024 .. 1536), or of 1-2 on a float32 matrix
+ * Calls of 1-4 dot / cosine queries with k <= 128 on an fp16 matrix (d = 256 .. 768; 1-2 queries for d = 1024 .. 1536), or of 1-2 on a float32 matrix
  * (d in {128,256,384}; one query at d = 768 and, from 1.5 M rows on, at d = 512), run as ONE kernel launch (query preparation, row sample, threshold exchange between the
  * workgroups, filter pass, final sort: hdb_mfma_fused.h); everything else is the same pipeline as separate launches.
  * Results are bit-identical either way. */

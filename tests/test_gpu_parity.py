@@ -1309,7 +1309,7 @@ def test_fuzz_gpu_against_oracle(orc):
 # ------------------------------------------------------------------------------------------------
 # 10. the single-launch pipeline (hdb_mfma_fused.h): 1-4 dot / cosine queries on fp16 matrices
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n,d", [(8193, 384), (8200 + 63, 128), (50_000, 768), (400_000, 256), (1_300_001, 384),
+@pytest.mark.parametrize("n,d", [(8193, 384), (8200 + 63, 256), (50_000, 768), (400_000, 256), (1_300_001, 384),
                                  (60_001, 1024), (300_000, 1536), (100_003, 1408), (150_000, 1152)])
 def test_single_launch_pipeline_equals_multi_kernel_and_oracle(orc, n, d):
     """Every call shape the fused kernel takes (1-4 queries, dot / cosine, k <= 128, bias, row mask, ragged last tile,

@@ -15,7 +15,7 @@ t0 = time.time()
 for case in range(cases):
     if time.time() - t0 > budget: break
     f16 = rng.random() < 0.65
-    d = int(rng.choice([128, 256, 384, 512, 640, 768, 1024, 1152, 1280, 1408, 1536])) if f16 else int(rng.choice([128, 256, 384, 512, 768]))
+    d = int(rng.choice([256, 384, 512, 640, 768, 1024, 1152, 1280, 1408, 1536])) if f16 else int(rng.choice([128, 256, 384, 512, 768]))
     size = rng.random()
     n = int(rng.integers(8200, 60_000)) if size < 0.5 else int(rng.integers(60_000, 600_000)) if size < 0.85 else int(rng.integers(600_000, 2_500_000))
     if not f16: n = min(n, 1_200_000)

@@ -6,7 +6,7 @@ from hyperdb._native import GpuIndex, METRIC_IDS
 import bench
 dev = torch.device('cuda', 0)
 mid = METRIC_IDS['cosine_similarity']
-for dt, d, n in ((torch.float16, 128, 10_000_000), (torch.float16, 256, 10_000_000), (torch.float16, 384, 10_000_000), (torch.float16, 512, 5_000_000),
+for dt, d, n in ((torch.float16, 256, 10_000_000), (torch.float16, 384, 10_000_000), (torch.float16, 512, 5_000_000),
                  (torch.float16, 640, 5_000_000), (torch.float16, 768, 5_000_000), (torch.float16, 1024, 4_000_000), (torch.float16, 1536, 2_500_000),
                  (torch.float32, 128, 5_000_000), (torch.float32, 256, 5_000_000), (torch.float32, 384, 4_000_000), (torch.float32, 768, 2_000_000),
                  (torch.float16, 384, 1_250_000), (torch.float16, 256, 1_250_000), (torch.float16, 1024, 500_000)):
