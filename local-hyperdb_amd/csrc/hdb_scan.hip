@@ -415,7 +415,8 @@ static void launch_scan_t(const ScanArgs& a, int nq_launch, int blocks, bool vec
         else hipLaunchKernelGGL((hdb_scan_generic_kernel<T, MODE, 0>), grid, dim3(256), lds, st, a, nq_end);
         return;
     }
-    const bool qt4 = nq_launch >= 3 && lds4 <= 60 * 1024;
+    // two queries already pay for the four-query kernel: one pass over V instead of two (float32 d=768, N=1M: 1 098 -> ~530 us)
+    const bool qt4 = nq_launch >= 2 && lds4 <= 60 * 1024;
     if (qt4) {
         if (accm == 1) launch_vec<T, 4, MODE, 1>(a, nq_launch, blocks, st);
         else if (accm == 2) launch_vec<T, 4, MODE, 2>(a, nq_launch, blocks, st);
@@ -439,7 +440,7 @@ extern "C" int hdb_launch_scan(const ScanArgs* args, int dtype, int mode, int nq
     // grid: every wave keeps a whole tile in flight.  With 12 KiB tiles (768-byte rows) 2 workgroups (8 waves) per CU
     // is the measured optimum (6.8 TB/s); with the 24 KiB tiles of the unrolled 1536-byte-row variant one workgroup
     // per CU is (N=1M fp32 d=384: 237 vs 246 us; N=10M: 7.02 vs 6.78 TB/s) -- the same ~100 KiB in flight per CU
-    const bool wide_rows = vec && a.row_bytes == 6 * 256 && nq_launch < 3;
+    const bool wide_rows = vec && a.row_bytes == 6 * 256 && nq_launch < 2;      // (the one-query kernel; two or more queries take the four-query one)
     const int auto_blocks = wide_rows ? 256 : 512;
     const int blocks = hdb_grid_for(a.ntiles, 4, max_blocks > 0 ? max_blocks : auto_blocks);
     if (dtype == HDB_F16) { if (mode == 0) launch_scan_t<__half, 0>(a, nq_launch, blocks, vec, st); else launch_scan_t<__half, 1>(a, nq_launch, blocks, vec, st); }

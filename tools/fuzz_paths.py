@@ -14,7 +14,7 @@ for case in range(cases):
     use16 = rng.random() < 0.75
     d = int(rng.choice(mfma_d)) if use16 else int(rng.choice([24, 100, 384, 200, 48, 128, 256, 512, 768]))
     n = int(rng.integers(8200, 400_000))
-    nq = int(rng.choice([1, 2, 5, 16, 17, 64, 128, 129, 200, 256, 257, 300])) if use16 else int(rng.choice([1, 3, 4, 6, 5, 40, 128, 129]))
+    nq = int(rng.choice([1, 2, 5, 16, 17, 64, 128, 129, 200, 256, 257, 300])) if use16 else int(rng.choice([1, 2, 3, 4, 6, 5, 40, 128, 129]))
     k = int(rng.choice([1, 7, 100, 128, 257, 1000]))
     names = ["dot_product", "cosine_similarity", "euclidean_metric", "pearson_correlation", "hamming_distance", "jaccard_similarity"]
     if not use16: names.append("manhattan_distance")
