@@ -416,7 +416,9 @@ static void launch_scan_t(const ScanArgs& a, int nq_launch, int blocks, bool vec
         return;
     }
     // two queries already pay for the four-query kernel: one pass over V instead of two (float32 d=768, N=1M: 1 098 -> ~530 us)
-    const bool qt4 = nq_launch >= 2 && lds4 <= 60 * 1024;
+    // (fp16 manhattan is VALU-bound in the four-query kernel -- 1 825 us for 5M x 384 against 625 per single-query pass: two
+    // queries stay with two passes there)
+    const bool qt4 = (nq_launch >= 3 || (nq_launch == 2 && !(accm == 2 && sizeof(T) == 2))) && lds4 <= 60 * 1024;
     if (qt4) {
         if (accm == 1) launch_vec<T, 4, MODE, 1>(a, nq_launch, blocks, st);
         else if (accm == 2) launch_vec<T, 4, MODE, 2>(a, nq_launch, blocks, st);
