@@ -47,7 +47,9 @@ int hdb_launch_maskbias(const uint8_t* mask, const float* bias, int64_t n, float
 int hdb_mfma_supported(int dtype, int d, int metric);
 int hdb_mfma_tile_rows(int dtype, int d);
 int hdb_launch_mfma_scan(const ScanArgs* args, int dtype, int mode, int nq_launch, const void* q16, const float* sqnorm,
-                         const float* qsq, const float* qscl, int max_blocks, int variant, void* stream);
+                         const float* qsq, const float* qscl, int max_blocks, int variant, void* stream, const BatchArgs* f);
+int hdb_mfma_batch_capacity(int dtype, int d);
+size_t hdb_mfma_batch_ctl_bytes(int wgs);
 int hdb_mfma_fused_supported(int dtype, int d, int metric, int nq, uint32_t kk);
 size_t hdb_mfma_fused_ctl_bytes(void);
 int hdb_launch_mfma_fused(const ScanArgs* args, int dtype, const FusedArgs* fa, int max_blocks, void* stream);
@@ -106,6 +108,8 @@ struct hdb_index {
     // control block of the single-launch pipeline (owned): counters + exchange granules, zero between calls
     char* fctl = nullptr;
     uint32_t fused_epoch = 0;
+    // ... and of the single-launch BATCHED pipeline (hdb_mfma_kernel.h, MODE 2): counters, threshold words, sample granules
+    char* bctl = nullptr;
     // device copy of the result record of hdb_topk_host (owned)
     char* rec = nullptr;
     size_t rec_bytes = 0;
@@ -121,10 +125,13 @@ struct hdb_index {
     int64_t exact_bytes = (int64_t)1 << 30;
     int64_t bits_fused = 1;           // hamming / jaccard: try the sampled-threshold path first (exact path when it fails)
     int64_t host_direct = 1;          // hdb_topk_host: kernels write a pinned host record themselves (no D2H copy)
-    int64_t dyn_tiles = 1;            // MFMA filter pass of up to 64 queries: hand tiles out from a counter (0: static split)
+    int64_t dyn_tiles = 1;            // MFMA filter pass: hand tiles out from a counter (0: static split)
+    int64_t dyn_min_mb = 16;          // ... for passes of at least this many MiB of V per workgroup
+    int64_t dyn_heavy = 1;            // ... also when all eight waves multiply
     int64_t host_poll = 1;            // hdb_topk_host + single-launch pipeline + pinned record: poll the status words instead of the stream
     int64_t use_fused = 1;            // 1-4 dot / cosine queries on an fp16 matrix: the whole call in ONE kernel (hdb_mfma_fused.h)
-    int64_t fused_timeout_us = 2000;  // bound of every in-kernel spin of that kernel
+    int64_t use_batch1 = 1;           // 5+ queries (euclidean: 1+) on the matrix cores, k <= 128: the whole call in ONE launch per <= 256 queries (needs use_fused)
+    int64_t fused_timeout_us = 2000;  // bound of every in-kernel spin of those kernels
     int64_t finalize_threads = 1024;  // workgroup size of hdb_finalize_kernel (256 | 512 | 1024)
     int64_t mfma_variant = 16;        // MFMA shape of the d=384 256-query pass (16 | 32)
     // stats of the last hdb_topk call
@@ -289,6 +296,7 @@ extern "C" void hdb_index_destroy(hdb_index* ix) {
     if (ix->pscale) (void)hipFree(ix->pscale);
     if (ix->mbias) (void)hipFree(ix->mbias);
     if (ix->fctl) (void)hipFree(ix->fctl);
+    if (ix->bctl) (void)hipFree(ix->bctl);
     if (ix->ws) (void)hipFree(ix->ws);
     if (ix->rec) (void)hipFree(ix->rec);
     for (hipEvent_t e : ix->ev_pool) (void)hipEventDestroy(e);
@@ -329,8 +337,11 @@ extern "C" int hdb_set_option(hdb_index* ix, const char* name, int64_t value) {
     else if (!strcmp(name, "mfma_variant")) { if (value == 16 || value == 32) ix->mfma_variant = value; }
     else if (!strcmp(name, "host_direct")) ix->host_direct = value;
     else if (!strcmp(name, "use_fused")) ix->use_fused = value;
+    else if (!strcmp(name, "use_batch1")) ix->use_batch1 = value;
     else if (!strcmp(name, "host_poll")) ix->host_poll = value;
     else if (!strcmp(name, "dyn_tiles")) ix->dyn_tiles = value;
+    else if (!strcmp(name, "dyn_min_mb")) ix->dyn_min_mb = std::max<int64_t>(0, value);
+    else if (!strcmp(name, "dyn_heavy")) ix->dyn_heavy = value;
     else if (!strcmp(name, "fused_timeout_us")) ix->fused_timeout_us = std::max<int64_t>(1, value);
     else if (!strcmp(name, "bits_fused")) ix->bits_fused = value;
     else if (!strcmp(name, "profile")) { ix->profile = value; ix->ev_used = 0; }
@@ -419,6 +430,7 @@ static void base_args(const hdb_index* ix, ScanArgs& a, const void* Q, int metri
     a.inv_norm = ix->inv_norm; a.mask = ix->mask;
     a.tile_stride = 1; a.ntiles = (ix->n + 15) / 16;
     a.cap = HDB_CAND_CAP;
+    a.dyn_min_bytes = ix->dyn_min_mb << 20; a.dyn_heavy = (int32_t)ix->dyn_heavy;
 }
 
 // One scan launch (VALU, hamming or MFMA flavour) for queries [a.q0, a.q0+cq).
@@ -428,7 +440,7 @@ static int run_scan(hdb_index* ix, ScanArgs& a, int mode, int cq, const QueryBuf
     if (is_bits_metric(a.metric)) {
         LAUNCH_TRY(hdb_launch_hamming(&a, mode, cq, ix->bits, ix->bits_npad, ix->W, qb.qbits, st));
     } else if (mfma) {
-        LAUNCH_TRY(hdb_launch_mfma_scan(&a, ix->dtype, mode, cq, qb.q16, ix->sqnorm, qb.qsq, qb.qscl, (int)ix->max_blocks, (int)ix->mfma_variant, st));
+        LAUNCH_TRY(hdb_launch_mfma_scan(&a, ix->dtype, mode, cq, qb.q16, ix->sqnorm, qb.qsq, qb.qscl, (int)ix->max_blocks, (int)ix->mfma_variant, st, nullptr));
     } else {
         LAUNCH_TRY(hdb_launch_scan(&a, ix->dtype, mode, cq, (int)ix->max_blocks, st));
     }
@@ -531,6 +543,11 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
                              // but 1 491 vs 1 466 at 5 M -- the single launch up to 4 M rows
                              !(ix->dtype == HDB_F16 && ix->d == 1024 && n > 4000000);
     const int tile_rows = (mfma || fused_shape) ? hdb_mfma_tile_rows(ix->dtype, ix->d) : 16;
+    // anything else the matrix-core scan takes (5-256 dot / cosine queries, 1-256 euclidean ones), k <= 128: one launch per
+    // <= bcap queries does preparation, sample, thresholds, the pass and every query's final sort (hdb_mfma_kernel.h, MODE 2)
+    const int bcap = mfma ? hdb_mfma_batch_capacity(ix->dtype, ix->d) : 0;
+    const bool batch1 = ix->use_fused && ix->use_batch1 && mfma && !fused_shape && !exact && !small && !full_sort && kk <= 128 &&
+                        dev_status != nullptr && !is_pearson && bcap > 0;
 
     // ---- plan the chunking --------------------------------------------------------------------
     int64_t s_tiles = 0, s_stride = 1; uint32_t m = 0;
@@ -538,7 +555,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     const int64_t s_rows = s_tiles * tile_rows;
     const int64_t ld_s = align_up((size_t)std::max<int64_t>(s_rows, 4), 4);
     const int64_t ld_n = align_up((size_t)n, 4);
-    int cq_max = 256;
+    int cq_max = batch1 ? bcap : 256;
     if (exact && !small) cq_max = (int)std::max<int64_t>(1, std::min<int64_t>(256, ix->exact_bytes / (ld_n * 4)));
     cq_max = std::min(cq_max, (int)nq);
 
@@ -570,7 +587,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     // the MFMA scan multiplies with fp16 queries: written by the same kernel (pearson converts its centred copy later)
     const bool f16_queries = mfma && ix->dtype == HDB_F16;          // fp32 matrices multiply with the float32 queries as they are
     const bool q16_in_prep = f16_queries && !is_pearson && !full_sort;
-    if (!fused) LAUNCH_TRY(hdb_launch_qprep(dev_Q, nq, ix->d, f64, qinv, qsq, qnan, q16_in_prep ? q16 : nullptr, qscl, st));
+    if (!fused && !batch1) LAUNCH_TRY(hdb_launch_qprep(dev_Q, nq, ix->d, f64, qinv, qsq, qnan, q16_in_prep ? q16 : nullptr, qscl, st));
     if (is_ham) {
         rc = ensure_bits(ix, st); if (rc) return rc;
         LAUNCH_TRY(hdb_launch_qsign(dev_Q, nq, ix->d, f64, W, qbits, st));
@@ -638,6 +655,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
         }
         ScanArgs a; base_args(ix, a, dev_Q, metric);
         a.bias = bias_eff; a.mask = nullptr;
+        if (metric == HDB_EUCLIDEAN) a.inv_norm = ix->sqnorm;          // the per-row aux value of the euclidean expansion
         a.ntiles = (n + tile_rows - 1) / tile_rows;
         a.thr = thr; a.cnt = cnt; a.cand = cand; a.nq = nq;
         FusedArgs fa; memset(&fa, 0, sizeof(fa));
@@ -654,6 +672,39 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
         prof_begin(ix, st);
         LAUNCH_TRY(hdb_launch_mfma_fused(&a, ix->dtype, &fa, (int)ix->max_blocks, st));
         prof_end(ix, st);
+        return HDB_OK;
+    }
+    if (batch1) {
+        const int cus = hdb_cu_count();
+        if (!ix->bctl) {
+            const size_t cb = hdb_mfma_batch_ctl_bytes(cus);
+            HIP_TRY(hipMalloc((void**)&ix->bctl, cb));
+            HIP_TRY(hipMemset(ix->bctl, 0, cb));
+        }
+        ix->st_sample_rows = s_rows; ix->st_sample_m = m; ix->st_chunks = 0; ix->st_path = 1; ix->st_mfma = 1; ix->st_fused = 2;
+        const size_t qrow = (size_t)ix->d * 4;
+        for (int q0 = 0; q0 < nq; q0 += cq_max) {
+            const int cq = std::min(cq_max, nq - q0);
+            ix->st_chunks++;
+            ScanArgs a; base_args(ix, a, dev_Q, metric);
+            a.bias = bias_eff; a.mask = nullptr; a.q0 = 0; a.nq = cq;
+            a.ntiles = (n + tile_rows - 1) / tile_rows;
+            a.cand = cand;
+            a.tile_ctr = ix->dyn_tiles ? reinterpret_cast<uint32_t*>(ix->bctl) + HDB_BATCH_CTL_TILE : nullptr;
+            BatchArgs fa; memset(&fa, 0, sizeof(fa));
+            fa.Qraw = static_cast<const char*>(dev_Q) + (size_t)q0 * qrow;
+            fa.s_tiles = s_tiles; fa.s_stride = s_stride;
+            ix->fused_epoch = (ix->fused_epoch + 1) & 0x7FFFFFFFu;
+            if (ix->fused_epoch == 0) ix->fused_epoch = 1;
+            fa.epoch = ix->fused_epoch;
+            fa.timeout_ticks = (uint32_t)std::min<int64_t>(ix->fused_timeout_us * 100, 0x7FFFFFFF);
+            fa.ctl = reinterpret_cast<uint32_t*>(ix->bctl);
+            fa.k = (uint32_t)k; fa.kk = kk; fa.row_base = ix->row_base;
+            fa.idx_out = dev_idx + (int64_t)q0 * k; fa.score_out = dev_score + (int64_t)q0 * k; fa.status = dev_status + q0;
+            prof_begin(ix, st);
+            LAUNCH_TRY(hdb_launch_mfma_scan(&a, ix->dtype, 2, cq, nullptr, ix->sqnorm, nullptr, nullptr, (int)ix->max_blocks, (int)ix->mfma_variant, st, &fa));
+            prof_end(ix, st);
+        }
         return HDB_OK;
     }
     bool q16_ready = q16_in_prep;

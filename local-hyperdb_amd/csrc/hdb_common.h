@@ -41,6 +41,8 @@ struct ScanArgs {
     int32_t nq;             // total number of queries behind Q
     int32_t raw;            // 1: keep NaN scores as NaN (per-metric functions); 0: NaN -> -inf (ranking)
     uint32_t* tile_ctr;     // MFMA filter pass: zeroed counter that hands out tiles dynamically (nullptr: static split)
+    int64_t dyn_min_bytes;  // ... only for passes of at least this many bytes of V per workgroup
+    int32_t dyn_heavy;      // ... also when all eight waves multiply (more than half of a launch's query capacity)
 };
 
 // Extra arguments of the single-launch top-k (hdb_mfma_fused.h): sample plan, exchange block, outputs.
@@ -57,6 +59,31 @@ struct FusedArgs {
     int64_t row_base;
     int64_t* idx_out; float* score_out; int32_t* status;
     float* thr_out;                 // [nq] thresholds (diagnostics)
+};
+
+// Extra arguments of the single-launch BATCHED top-k (hdb_mfma_kernel.h, MODE 2): up to 256 queries, one launch does query
+// preparation, the strided row sample, the per-query thresholds, the filter pass over all rows and every query's final top-k.
+// Control block (BatchArgs::ctl, zero when allocated and again when a launch has finished), in 32-bit words:
+//   [0] workgroups done with the filter pass, [1] workgroups that left the kernel, [32] tile counter (a line of its own),
+//   [64] abort word, [128 .. 128+256) candidates appended per query.  Byte 2048: 256 threshold granules {epoch, key};
+//   byte 4096: sample granules [query][workgroup][8] x {epoch, key}.
+#define HDB_BATCH_MAXQ 256
+#define HDB_BATCH_CTL_DONE 0
+#define HDB_BATCH_CTL_EXIT 1
+#define HDB_BATCH_CTL_TILE 32
+#define HDB_BATCH_CTL_ABORT 64
+#define HDB_BATCH_CTL_CNT 128
+#define HDB_BATCH_THRW_BYTE 2048
+#define HDB_BATCH_GRAN_BYTE 4096
+struct BatchArgs {
+    const void* Qraw;               // [nq][d] queries as the caller passed them (float32)
+    int64_t s_tiles, s_stride;      // strided row sample (tiles of R rows)
+    uint32_t epoch;                 // != 0, different for every launch on this control block
+    uint32_t timeout_ticks;         // s_memrealtime ticks (100 MHz) a spin may last
+    uint32_t* ctl;
+    uint32_t k, kk;
+    int64_t row_base;
+    int64_t* idx_out; float* score_out; int32_t* status;
 };
 
 // ---- fp16 copy of a query for the matrix pipe ----------------------------------------------------------
@@ -130,6 +157,17 @@ __device__ __forceinline__ A hdb_rows4_sum(A a0, A a1, A a2, A a3, int l16) {
     w += hdb_dpp<HDB_DPP_XOR2>(w);
     w += hdb_dpp<HDB_DPP_XOR1>(w);
     return w;
+}
+// Wave-wide maximum of a 32-bit key in every lane: four DPP steps inside each 16-lane row, then the four row maxima through
+// v_readlane (the shuffle form is six dependent LDS-crossbar round trips: 8 rounds of it cost the threshold exchange ~2 us).
+__device__ __forceinline__ uint32_t hdb_wave_max_dpp(uint32_t v) {
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, HDB_DPP_XOR1, 0xF, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, HDB_DPP_XOR2, 0xF, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, HDB_DPP_HALF_MIRROR, 0xF, 0xF, false));
+    v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, HDB_DPP_MIRROR, 0xF, 0xF, false));
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return max(max(a, b), max(c, d));
 }
 __device__ __forceinline__ int hdb_owned_row(int l16) { return ((l16 >> 2) & 1) * 2 + ((l16 >> 3) & 1); }
 

@@ -97,10 +97,15 @@ static __device__ uint32_t hdb_preselect(unsigned long long* buf, uint32_t nc, u
 // With `floor_ptr` the function returns, to every thread, whether the kk-th best candidate scores ABOVE
 // canon(*floor_ptr * floor_mul), i.e. whether at least kk candidates do (the list may hold entries that only some
 // workgroups collected, see hdb_mfma_fused.h; ctl word 8).  The load of *floor_ptr overlaps the candidate loads.
+// `fix(buf, nc)` runs on the candidates once they are in LDS (all threads call it; it ends with a barrier of its own if it
+// writes): the single-launch batched scan re-scores euclidean near-duplicates there (hdb_mfma_kernel.h).
+struct HdbNoFix { __device__ __forceinline__ void operator()(unsigned long long*, uint32_t) const {} };
+template <typename Fix = HdbNoFix>
 __device__ __forceinline__ uint32_t hdb_finalize_body(unsigned long long* buf, const unsigned long long* cand, uint32_t total, int q,
                                                       uint32_t cap, uint32_t k, uint32_t kk /* min(k, n) */, int64_t row_base,
                                                       int64_t* idx_out, float* score_out, int32_t* status, int qnan_flag,
-                                                      int32_t extra_status, const float* floor_ptr = nullptr, float floor_mul = 1.f) {
+                                                      int32_t extra_status, const float* floor_ptr = nullptr, float floor_mul = 1.f,
+                                                      const Fix& fix = Fix()) {
     unsigned long long* scratch = buf + cap;
     uint32_t* hist = reinterpret_cast<uint32_t*>(scratch + cap);
     uint32_t* ctl = hist + 2048;                    // 16 words
@@ -113,6 +118,7 @@ __device__ __forceinline__ uint32_t hdb_finalize_body(unsigned long long* buf, c
     }
     for (uint32_t i = threadIdx.x; i < nc; i += blockDim.x) buf[i] = cand[i];      // `cand` = this query's list
     __syncthreads();
+    fix(buf, nc);
     const uint32_t floor_key = floor_ptr ? hdb_f2key(hdb_canon(floor_v * floor_mul)) : 0u;
     HDB_FIN_STAMP(9);
     uint32_t ns = nc;

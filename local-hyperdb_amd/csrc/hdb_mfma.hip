@@ -88,6 +88,15 @@ extern "C" int hdb_mfma_tile_rows(int dtype, int d) {
     return 0;
 }
 
+// queries ONE launch of the MFMA scan covers (grid.y == 1): what a single-launch (mode 2) call can take
+extern "C" int hdb_mfma_batch_capacity(int dtype, int d) {
+    if (hdb_mfma_tile_rows(dtype, d) <= 0) return 0;
+    if (dtype == HDB_F32) return 128;
+    return (d == 384 || d == 128 || d == 256 || d == 512 || d == 640) ? 256 : 128;      // two query tiles per wave (hdb_mfma_qt2.hip)
+}
+// bytes of the control block of the single-launch batched call for a grid of `wgs` workgroups
+extern "C" size_t hdb_mfma_batch_ctl_bytes(int wgs) { return (size_t)HDB_BATCH_GRAN_BYTE + (size_t)HDB_BATCH_MAXQ * (size_t)wgs * 8 * 8; }
+
 extern "C" int hdb_mfma_supported(int dtype, int d, int metric) {
     return hdb_mfma_tile_rows(dtype, d) > 0 && (metric == HDB_DOT || metric == HDB_COSINE || metric == HDB_EUCLIDEAN);
 }
@@ -97,18 +106,26 @@ extern "C" int hdb_mfma_supported(int dtype, int d, int metric) {
 // for N=10M, Q=256), 32 = 32x32x16 with one query tile per wave (kept for A/B measurements).
 // (per index: hdb_set_option(ix, "mfma_variant", 16 | 32), passed down as `variant`)
 
+#define HDB_GEOM_DECL(name) extern "C" int name(const ScanArgs* args, int mode, int nq_launch, const void* q16, const float* sqnorm, \
+                                              const float* qsq, const float* qscl, int blocks, int variant, void* stream, const BatchArgs* f)
+HDB_GEOM_DECL(hdb_launch_mfma_scan_f16_d384);       // hdb_mfma_d384.hip
+HDB_GEOM_DECL(hdb_launch_mfma_scan_f16_narrow);     // hdb_mfma_narrow.hip
+HDB_GEOM_DECL(hdb_launch_mfma_scan_f16_mid);        // hdb_mfma_mid.hip
+HDB_GEOM_DECL(hdb_launch_mfma_scan_f16_1k);         // hdb_mfma_1k.hip
 extern "C" int hdb_mfma_qt2_supported(int d);
 extern "C" int hdb_launch_mfma_scan_f16_qt2(const ScanArgs* args, int mode, int nq_launch, const void* q16, const float* sqnorm,
-                                            const float* qsq, const float* qscl, int blocks, void* stream);
+                                            const float* qsq, const float* qscl, int blocks, void* stream, const BatchArgs* f);
 extern "C" int hdb_launch_mfma_scan_f32(const ScanArgs* args, int mode, int nq_launch, const void* q, const float* sqnorm,
-                                        const float* qsq, int blocks, void* stream);
+                                        const float* qsq, int blocks, void* stream, const BatchArgs* f);
 extern "C" int hdb_launch_mfma_scan_f16_wide(const ScanArgs* args, int mode, int nq_launch, const void* q16, const float* sqnorm,
-                                             const float* qsq, const float* qscl, int blocks, void* stream);
+                                             const float* qsq, const float* qscl, int blocks, void* stream, const BatchArgs* f);
 
 // a.ntiles / a.tile_stride are in units of hdb_mfma_tile_rows(dtype, d) rows here.  q: the query fragments' source --
 // scaled fp16 copies (+ qscl) for fp16 matrices, the float32 queries themselves (qscl = nullptr) for fp32 ones.
+// mode 2 = the whole call in one launch (hdb_mfma_kernel.h): f != nullptr, nq_launch <= hdb_mfma_batch_capacity(), grid = one
+// workgroup per CU at most (the in-kernel exchange needs the grid co-resident)
 extern "C" int hdb_launch_mfma_scan(const ScanArgs* args, int dtype, int mode, int nq_launch, const void* q16, const float* sqnorm,
-                                    const float* qsq, const float* qscl, int max_blocks, int variant, void* stream) {
+                                    const float* qsq, const float* qscl, int max_blocks, int variant, void* stream, const BatchArgs* f) {
     const int g_mfma_variant = variant == 32 ? 32 : 16;
     const ScanArgs& a = *args;
     hipStream_t st = (hipStream_t)stream;
@@ -120,23 +137,18 @@ extern "C" int hdb_launch_mfma_scan(const ScanArgs* args, int dtype, int mode, i
     int blocks = (int)(a.ntiles < want ? a.ntiles : want);
     if (max_blocks > 0 && max_blocks < blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
-    if (dtype == HDB_F32) return hdb_launch_mfma_scan_f32(args, mode, nq_launch, q16, sqnorm, qsq, blocks, stream);
+    if (mode == 2 && blocks > cus) blocks = cus;
+    if (dtype == HDB_F32) return hdb_launch_mfma_scan_f32(args, mode, nq_launch, q16, sqnorm, qsq, blocks, stream, f);
     if (dtype != HDB_F16) return (int)hipErrorNotSupported;
     if (nq_launch > 128 && hdb_mfma_qt2_supported(a.d) && g_mfma_variant != 32)
-        return hdb_launch_mfma_scan_f16_qt2(args, mode, nq_launch, q16, sqnorm, qsq, qscl, blocks, stream);
+        return hdb_launch_mfma_scan_f16_qt2(args, mode, nq_launch, q16, sqnorm, qsq, qscl, blocks, stream, f);
+    const int v = g_mfma_variant;
     switch (a.d) {
-        case 128: return launch_mode<_Float16, 16, 1, 128, 64>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
-        case 256: return launch_mode<_Float16, 16, 1, 256, 64>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
-        case 384:
-            if (nq_launch > 128 && g_mfma_variant == 32) return launch_mode<_Float16, 32, 1, 384, 64>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
-            if (nq_launch > 128) return launch_mode<_Float16, 16, 2, 384, 64>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
-            return launch_mode<_Float16, 16, 1, 384, 64>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
-        case 512: return launch_mode<_Float16, 16, 1, 512, 32>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
-        case 640: return launch_mode<_Float16, 16, 1, 640, 32>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
-        case 768: return launch_mode<_Float16, 16, 1, 768, 32>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
-        case 1024: return launch_mode<_Float16, 16, 1, 1024, 16>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
-        case 1536: return launch_mode<_Float16, 16, 1, 1536, 16>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
-        default: return hdb_launch_mfma_scan_f16_wide(args, mode, nq_launch, q16, sqnorm, qsq, qscl, blocks, stream);     // 896, 1152, 1280, 1408
+        case 128: case 256: return hdb_launch_mfma_scan_f16_narrow(args, mode, nq_launch, q16, sqnorm, qsq, qscl, blocks, v, stream, f);
+        case 384: return hdb_launch_mfma_scan_f16_d384(args, mode, nq_launch, q16, sqnorm, qsq, qscl, blocks, v, stream, f);
+        case 512: case 640: case 768: return hdb_launch_mfma_scan_f16_mid(args, mode, nq_launch, q16, sqnorm, qsq, qscl, blocks, v, stream, f);
+        case 1024: case 1536: return hdb_launch_mfma_scan_f16_1k(args, mode, nq_launch, q16, sqnorm, qsq, qscl, blocks, v, stream, f);
+        default: return hdb_launch_mfma_scan_f16_wide(args, mode, nq_launch, q16, sqnorm, qsq, qscl, blocks, stream, f);     // 896, 1152, 1280, 1408
     }
 }
 
@@ -159,10 +171,3 @@ extern "C" int hdb_launch_rescore_euclid(unsigned long long* cand, const uint32_
     return (int)hipGetLastError();
 }
 
-#if HDB_MFMA_CLOCK
-// Diagnostic build only: copy the stamps of the last launch of THIS translation unit's kernels (d = 384 lives here).
-extern "C" int hdb_debug_read_clock(unsigned long long* host_out, int wgs) {
-    if (wgs > HDB_CLOCK_WGS) wgs = HDB_CLOCK_WGS;
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(hdb_clock_buf), (size_t)wgs * 4 * sizeof(unsigned long long));
-}
-#endif

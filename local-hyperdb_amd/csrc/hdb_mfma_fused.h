@@ -31,7 +31,7 @@
 // host re-runs the call through the exact path (and resets the control block).  This only happens when the grid is
 // not co-resident (another kernel holds CUs), never on an idle GPU: grid <= CU count, one workgroup fits per CU.
 #pragma once
-#include "hdb_mfma_kernel.h"
+#include <hip/hip_runtime.h>
 
 // Diagnostic build only (tools/stamps_fused.py; product: 0): wall-clock stamps (s_memrealtime, 100 MHz) of the phases
 // of every workgroup, stored in a buffer of their own that nothing reads: [wg][8] = start, prologue done, published,
@@ -48,7 +48,7 @@ static __device__ unsigned long long hdb_fused_stamps[16 * HDB_CLOCK_WGS_F];
 #define HDB_STAMP(slot) do { } while (0)
 #endif
 
-#include "hdb_finalize.h"
+#include "hdb_mfma_kernel.h"          // (includes hdb_finalize.h: the stamp macros above must come first)
 
 #define HDB_FUSED_MAXQ 4            // queries per fused call
 #define HDB_FUSED_M 8               // sample order statistic (k <= 128)
@@ -67,26 +67,6 @@ static __device__ unsigned long long hdb_fused_stamps[16 * HDB_CLOCK_WGS_F];
 #define HDB_FUSED_PEND 8            // filter tiles whose scores can be parked in LDS while no threshold is known yet: this many for
                                     // the most queries a flavour takes, up to 16 for fewer (same bytes)
 
-
-// LDS accesses in inline asm: hipcc cannot prove them disjoint from the ring that LDS-DMA writes and would drain the
-// wave's in-flight staging (s_waitcnt vmcnt(0)) in front of every one of them.
-__device__ __forceinline__ void hdb_lds_st32(unsigned int addr, float v) {
-    asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(v) : "memory");
-}
-__device__ __forceinline__ void hdb_lds_st16(unsigned int addr, unsigned int v) {
-    asm volatile("ds_write_b16 %0, %1" :: "v"(addr), "v"(v) : "memory");
-}
-__device__ __forceinline__ void hdb_lds_st128(unsigned int addr, f32x4 v) {
-    asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(v) : "memory");
-}
-__device__ __forceinline__ float hdb_lds_ld32(unsigned int addr) {
-    float v;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
-    return v;
-}
-
-typedef __attribute__((address_space(1))) unsigned long long hdb_gu64;
-typedef __attribute__((address_space(1))) unsigned int hdb_gu32;
 
 // E = _Float16: wave 0 multiplies on the matrix cores (fp16 copies of the queries as B fragments).
 // E = float (the reference's default fp_precision, BASELINE config 2): wave 0 computes the float32 dot products in the
@@ -124,7 +104,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     static_assert(R % MF == 0 && R <= 64 && (R * CPR) % 256 == 0 && ROWB % 256 == 0, "tile geometry");
     static_assert(!BLDS || (RT == 1 && 2 * D * 2 + 2048 <= HDB_MFMA_CB * 8), "LDS-resident fragments: 16-row tiles, two queries behind 2 KiB of list");
     static_assert(!VALU || (NJ * VQ <= 12 && (NP % 2 == 0 || NP == 1)), "float32 flavour: query chunks in registers, one or two computing waves");
-    static_assert(METRIC == 0 || METRIC == 1, "dot / cosine");
+    static_assert(METRIC == 0 || METRIC == 1 || (METRIC == 2 && !VALU), "dot / cosine; euclidean (||v||^2 + ||q||^2 - 2 v.q, aux0 = ||v||^2) on the matrix cores only");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* auxbuf = reinterpret_cast<float*>(smem + 3 * STAGE);                    // [3 stages][2][64]
@@ -142,7 +122,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     float* pbuf = VALU ? qpar + 16 : reinterpret_cast<float*>(cb);
     static_assert(HDB_FUSED_PEND * HDB_FUSED_MAXQ * 64 * 4 <= HDB_MFMA_CB * 8, "parked MFMA scores live in the candidate list");
     static_assert(!BLDS || 16 * 2 * R * 4 <= 2048, "parked scores of 16 tiles x 2 queries fit the first 2 KiB");
-    constexpr bool PARK = VALU || D <= 640 || BLDS;       // d = 768 would spill with it: there the selector holds the round as before
+    constexpr bool PARK = VALU || (D <= 640 && !(METRIC == 2 && D > 512)) || BLDS;       // d = 768 (euclidean: d = 640 too) would spill with it: there the selector holds the round as before
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -297,6 +277,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
         if (lane == 0) {
             const float qinv = (ss == 0.f) ? 1.0f : 1.0f / sqrtf(ss);
             hdb_lds_st32(qpar_addr + (unsigned int)w * 4u, (METRIC == 1 ? qinv : 1.0f) * (1.f / scale));
+            if (METRIC == 2) hdb_lds_st32(qpar_addr + (unsigned int)(3 * HDB_FUSED_MAXQ + w) * 4u, ss);      // ||q||^2
             hdb_lds_st32(qpar_addr + (unsigned int)(HDB_FUSED_MAXQ + w) * 4u, (ss != ss) ? 1.f : 0.f);
             hdb_lds_st32(qpar_addr + (unsigned int)(2 * HDB_FUSED_MAXQ + w) * 4u, __builtin_nanf(""));      // threshold: none yet
         }
@@ -307,7 +288,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     // ---- wave 0: B fragments and per-query constants ---------------------------------------------
     const bool q_ok = rl < nq;
     Vec Bq[(VALU || BLDS) ? 1 : KS];
-    float qinv_l = 1.f;
+    float qinv_l = 1.f, qsq_l = 0.f;
     // VALU flavour: lane (group g = lane >> 4, l16 = lane & 15) holds chunks l16 + 16 j of every query, and the per-query
     // multipliers / thresholds as wave-uniform values
     const int l16 = lane & 15, g4 = lane >> 4;
@@ -329,6 +310,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
             }
         } else if constexpr (BLDS) {
             if (q_ok) qinv_l = hdb_lds_ld32(qpar_addr + (unsigned int)rl * 4u);
+            if (METRIC == 2 && q_ok) qsq_l = hdb_lds_ld32(qpar_addr + (unsigned int)(3 * HDB_FUSED_MAXQ + rl) * 4u);
         } else {
             const unsigned int src = qlds_addr + (unsigned int)((q_ok ? rl : 0) * D) * 2u + (unsigned int)h * 16u;
 #pragma unroll
@@ -344,6 +326,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                 if (!q_ok) Bq[s] = Vec{0, 0, 0, 0, 0, 0, 0, 0};
             }
             if (q_ok) qinv_l = hdb_lds_ld32(qpar_addr + (unsigned int)rl * 4u);
+            if (METRIC == 2 && q_ok) qsq_l = hdb_lds_ld32(qpar_addr + (unsigned int)(3 * HDB_FUSED_MAXQ + rl) * 4u);
         }
     }
 
@@ -409,7 +392,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                     for (int j = 0; j < 4; ++j) {
                         const float x = tv[rt][j];
                         if (x >= thr_cmp && q_ok && rowg + j < n_rows && !(HAS_BIAS && x == -INFINITY)) {
-                            const float sc = hdb_canon(HAS_BIAS ? x : x * qinv_l);
+                            const float sc = hdb_canon((HAS_BIAS || METRIC == 2) ? x : x * qinv_l);
                             unsigned int pos = CB;
                             if (!(PARK && direct)) asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
                                                       : "=&v"(pos) : "v"(ctl_addr), "v"(1u) : "memory");
@@ -943,8 +926,13 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float dot = acc[rt][j];
-                            const float raw = METRIC == 1 ? dot * aj[j] : dot;
-                            acc[rt][j] = HAS_BIAS ? fmaf(raw, qinv_l, bj[j]) : raw;
+                            if constexpr (METRIC == 2) {     // the batched kernel's expression (hdb_mfma_kernel.h): bit-identical scores
+                                const float d2 = fmaxf(fmaf(-2.f * qinv_l, dot, aj[j] + qsq_l), 0.f);
+                                acc[rt][j] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_sqrtf(d2)) + (HAS_BIAS ? bj[j] : 0.f);
+                            } else {
+                                const float raw = METRIC == 1 ? dot * aj[j] : dot;
+                                acc[rt][j] = HAS_BIAS ? fmaf(raw, qinv_l, bj[j]) : raw;
+                            }
                         }
                     }
                 }
@@ -999,12 +987,14 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
         // published (nobody used a higher one), so the top-k is exact iff at least kk candidates score above it -- counting
         // all candidates would let the extras hide an underflow (clustered rows in a sample tile: 72 above, 100+ collected).
         float floor_mul[HDB_FUSED_MAXQ];             // thr_out is in the comparison domain: x this = score domain of the entries
+        float qsq_fin[HDB_FUSED_MAXQ];               // euclidean: ||q||^2 for the re-score of near-duplicates
 #pragma unroll
         for (int q = 0; q < HDB_FUSED_MAXQ; ++q) {
-            floor_mul[q] = 1.f;
+            floor_mul[q] = 1.f; qsq_fin[q] = 0.f;
             if (q < nq) {
                 if (qpar[HDB_FUSED_MAXQ + q] != 0.f) qnan_bits |= 1u << q;
-                if (!HAS_BIAS) floor_mul[q] = qpar[q];
+                if (!HAS_BIAS && METRIC != 2) floor_mul[q] = qpar[q];
+                if (METRIC == 2) qsq_fin[q] = qpar[3 * HDB_FUSED_MAXQ + q];
             }
         }
         __syncthreads();                             // everyone has its copy: fbuf may now cover ctl / qpar
@@ -1015,11 +1005,37 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
         for (int q = 0; q < nq; ++q) {
             const uint32_t tot0 = __hip_atomic_load(f.ctl + 2 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t tot = aborted ? 0u : tot0;
-            float fm = 1.f;
+            float fm = 1.f, ssq = 0.f;
 #pragma unroll
-            for (int qq = 0; qq < HDB_FUSED_MAXQ; ++qq) if (qq == q) fm = floor_mul[qq];
+            for (int qq = 0; qq < HDB_FUSED_MAXQ; ++qq) if (qq == q) { fm = floor_mul[qq]; ssq = qsq_fin[qq]; }
+            // euclidean scores come from ||v||^2 + ||q||^2 - 2 v.q, which cancels when v ~ q: candidates closer than 5 % of
+            // ||q||^2 are re-scored from the stored row with the direct difference (hdb_rescore_euclid_kernel, reference :49)
+            auto rescore = [&](unsigned long long* buf, uint32_t nc) {
+                if constexpr (METRIC == 2) {
+                    const float* qv = f.Qraw + (int64_t)q * D;
+                    const float close2 = 0.05f * ssq;
+                    const E* Vr = static_cast<const E*>(a.V);
+                    for (uint32_t e = (uint32_t)w; e < nc; e += 8u) {
+                        const unsigned long long ent = buf[e];
+                        const uint32_t row = 0xFFFFFFFFu - (uint32_t)(ent & 0xFFFFFFFFull);
+                        float sv = hdb_key2f((uint32_t)(ent >> 32));
+                        const float bb = HAS_BIAS ? a.bias[row] : 0.f;
+                        const float sim = sv - bb;
+                        const float dist = 1.f / sim - 1.f;
+                        if (sim > 0.f && dist * dist < close2) {           // wave-uniform: one entry per wave
+                            float accd = 0.f;
+                            for (int kx = lane; kx < D; kx += 64) { const float df = (float)Vr[(int64_t)row * D + kx] - qv[kx]; accd += df * df; }
+#pragma unroll
+                            for (int o = 32; o > 0; o >>= 1) accd += __shfl_xor(accd, o, 64);
+                            sv = hdb_canon(1.f / (1.f + sqrtf(accd)) + bb);
+                            if (lane == 0) buf[e] = hdb_pack(sv, row);
+                        }
+                    }
+                    __syncthreads();
+                }
+            };
             const uint32_t kth_above = hdb_finalize_body(fbuf, f.cand + (int64_t)q * f.cap, tot, q, f.cap, f.k, f.kk, f.row_base, f.idx_out,
-                                                       f.score_out, nullptr, 0, 0, f.thr_out + q, fm);
+                                                       f.score_out, nullptr, 0, 0, f.thr_out + q, fm, rescore);
             if (tid == q) {
                 const uint32_t nc = tot < f.cap ? tot : f.cap;
                 my_status = (tot > f.cap ? HDB_Q_OVERFLOW : 0) | ((nc < f.kk || (f.kk > 0 && !kth_above)) ? HDB_Q_UNDERFLOW : 0) | (((qnan_bits >> q) & 1u) ? HDB_Q_NAN : 0);
@@ -1057,5 +1073,7 @@ static int launch_fused(const ScanArgs& a, const FusedArgs& f, int blocks, hipSt
     const bool bias = a.bias != nullptr;
     if (a.metric == HDB_DOT) return bias ? launch_fused_one<E, VQ, D, R, 0, true>(a, f, nullptr, blocks, st) : launch_fused_one<E, VQ, D, R, 0, false>(a, f, nullptr, blocks, st);
     if (a.metric == HDB_COSINE) return bias ? launch_fused_one<E, VQ, D, R, 1, true>(a, f, a.inv_norm, blocks, st) : launch_fused_one<E, VQ, D, R, 1, false>(a, f, a.inv_norm, blocks, st);
+    if constexpr (sizeof(E) == 2 && D != 768)       // euclidean: a.inv_norm carries ||v||^2 (set by the host); d = 768 spills 3 registers with it
+        if (a.metric == HDB_EUCLIDEAN) return bias ? launch_fused_one<E, VQ, D, R, 2, true>(a, f, a.inv_norm, blocks, st) : launch_fused_one<E, VQ, D, R, 2, false>(a, f, a.inv_norm, blocks, st);
     return (int)hipErrorNotSupported;
 }

@@ -14,7 +14,10 @@ extern "C" int hdb_mfma_fused_supported(int dtype, int d, int metric, int nq, ui
                        (dtype == HDB_F32 && (d == 128 || d == 256 || d == 384 || d == 512 || d == 768));   // float32: VALU flavour
     // float32 queries live in registers as d/4 floats per lane group: 48 registers = 2 queries up to d = 384, 1 beyond
     const int maxq = dtype == HDB_F32 ? (d <= 384 ? 2 : 1) : (d <= 768 ? HDB_FUSED_MAXQ : 2);
-    return shape && (metric == HDB_DOT || metric == HDB_COSINE) && nq >= 1 && nq <= maxq && kk <= 128;
+    // euclidean (the MFMA expansion + direct re-score of near-duplicates in the last workgroup): fp16 matrices only -- the
+    // float32 VALU pipelines compute the direct difference, which this kernel's float32 flavour does not; d = 768 would spill
+    // three registers (those calls take the batched single launch, hdb_mfma_kernel.h MODE 2)
+    return shape && (metric == HDB_DOT || metric == HDB_COSINE || (metric == HDB_EUCLIDEAN && dtype == HDB_F16 && d != 768)) && nq >= 1 && nq <= maxq && kk <= 128;
 }
 
 // bytes of the persistent control block: 64 words of counters + the granules

@@ -3,6 +3,7 @@
 #pragma once
 #include "hdb_common.h"
 #include "../../include/hyperdb_hip.h"
+#include "hdb_finalize.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -22,6 +23,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // is d(memtime) / d(memrealtime) x 100 MHz.
 #ifndef HDB_MFMA_CLOCK
 #define HDB_MFMA_CLOCK 0
+#endif
+// Diagnostic build only (tools/stamps_batch1.py; product: 0): wall-clock stamps (s_memrealtime, 100 MHz) of the phases of
+// the single-launch batched call, per workgroup, in a buffer of their own that nothing reads: [wg][16] = 0 start,
+// 1 queries prepared, 2 sample pass done, 3 published, 4 owner done, 5 thresholds known, 6 filter pass done, 7 arrived,
+// 8 everybody arrived, 9 own queries sorted, 10 left.
+#ifndef HDB_BATCH_STAMPS
+#define HDB_BATCH_STAMPS 0
+#endif
+#if HDB_BATCH_STAMPS
+static __device__ unsigned long long hdb_batch_stamps[16 * 1024];
+#define HDB_BSTAMP(slot) do { if (ONE && tid == 0 && blockIdx.x < 1024) hdb_batch_stamps[16 * blockIdx.x + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define HDB_BSTAMP(slot) do { } while (0)
 #endif
 #if HDB_MFMA_CLOCK
 #define HDB_CLOCK_WGS 1024
@@ -87,6 +101,39 @@ __device__ __forceinline__ void hdb_lds_barrier() {
     __builtin_amdgcn_s_barrier();
 }
 
+// LDS accesses in inline asm: hipcc cannot prove them disjoint from the ring that LDS-DMA writes and would drain the
+// wave's in-flight staging (s_waitcnt vmcnt(0)) in front of every one of them.
+__device__ __forceinline__ void hdb_lds_st32(unsigned int addr, float v) {
+    asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void hdb_lds_st16(unsigned int addr, unsigned int v) {
+    asm volatile("ds_write_b16 %0, %1" :: "v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void hdb_lds_st128(unsigned int addr, f32x4 v) {
+    asm volatile("ds_write_b128 %0, %1" :: "v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ float hdb_lds_ld32(unsigned int addr) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+
+// 16-byte agent-scope (sc1) store and a pair of 16-byte sc1 loads: the exchange granules {epoch, key} travel two at a time
+// (an 8-byte sc1 store is one fabric write of its own; four lanes storing 16 bytes each fill a 64-byte line in one)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void hdb_st128_sc1(const void* p, u32x4 v) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void hdb_ld128x2_sc1(const void* p0, const void* p1, u32x4& a, u32x4& b) {
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b) : "v"(p0), "v"(p1) : "memory");
+}
+typedef __attribute__((address_space(1))) unsigned long long hdb_gu64;
+typedef __attribute__((address_space(1))) unsigned int hdb_gu32;
+
+
+template <int V> struct HdbIC { static constexpr int value = V; };
+
 // MF: rows / queries per MFMA tile; E: element type of V and of the query fragments.  CPS = 16-byte chunks per k-step
 // (one ds_read_b128 per lane and k-step: lane group h = lane / MF holds chunk CPS*s + h of its row).
 template <int MF, typename E> struct MfmaShape;
@@ -117,10 +164,29 @@ template <> struct MfmaShape<16, float> {
 // METRIC: 0 dot, 1 cosine (aux0 = 1/||v||), 2 euclidean similarity (aux0 = ||v||^2)
 // Fragment maps (lane l):  MF=32: row/query l&31, k = 16s + 8(l>>5) + j, C reg e -> row (e&3) + 8(e>>2) + 4(l>>5)
 //                          MF=16: row/query l&15, k = 32s + 8(l>>4) + j, C reg e -> row 4(l>>4) + e
+// MODE: 0 = store the scores (a.scores), 1 = filter against a.thr into the candidate lists, 2 = THE WHOLE CALL IN ONE LAUNCH
+// for up to (8 / RS) * MF * QT queries (grid.y == 1, one persistent workgroup per CU):
+//   prologue  every wave prepares its own queries from the caller's float32 vectors (hdb_qprep_kernel's sums in the same
+//             order, so 1/||q|| and ||q||^2 are bit-identical; power-of-two scaled fp16 copies straight into the B fragments);
+//   phase A   workgroup b multiplies tiles b, b+G, ... of the strided, jittered row sample (the plan of the multi-kernel
+//             pipeline); every lane keeps the TWO largest comparable values it has seen per query tile (a lane sees
+//             16 rows x RT of a tile for one query: with ~5 sample tiles per workgroup three of a query's top 8 land on one
+//             of its 1024 lanes with probability 5e-5, and then only make the threshold a little less selective);
+//   exchange  the lanes publish their two values as {epoch, key} granules [query][workgroup][8]; the OWNER of query q
+//             (workgroup q mod G) sweeps that query's G x 8 granules until all carry this call's epoch, takes the 8-th
+//             largest (a lower bound of the 8-th largest sample score: order statistic of a subset) and publishes it as
+//             one {epoch, key} word; every workgroup polls the nq words.  The first two filter tiles are in flight meanwhile;
+//   phase B   the filter pass over all rows (MODE 1's loop); survivors go to the global per-query lists;
+//   finish    drain, agent-scope release, arrive; when every workgroup has arrived, the owner of each query sorts its
+//             list in the (now free) ring LDS and writes its k results and its status word (euclidean: near-duplicates
+//             are re-scored directly first, hdb_rescore_euclid_kernel's arithmetic); the last workgroup to leave zeroes
+//             the control block.
+// Every spin is bounded (s_memrealtime); a workgroup that gives up raises the abort word, which turns the statuses into
+// HDB_Q_UNDERFLOW so that the host re-runs those queries through the exact path.
 template <typename E, int MF, int QT, int D, int R, int RS, int MODE, int METRIC, bool HAS_BIAS>
 __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __restrict__ q16,
                                                        const float* __restrict__ aux0g, const float* __restrict__ qsq, const float* __restrict__ qscl,
-                                                       int nq_end) {
+                                                       int nq_end, BatchArgs f) {
     using Shape = MfmaShape<MF, E>;
     using Vec = typename Shape::Vec;
     constexpr int ES = (int)sizeof(E);          // bytes per element
@@ -140,14 +206,24 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
     constexpr int QPW = MF * QT;                // queries per wave (QT query tiles share every A fragment)
     static_assert(R % (MF * RS) == 0 && 8 % RS == 0 && R <= 64 && (R * CPR) % 256 == 0 && ROWB % 256 == 0 && PPL + NAUX <= 31, "tile geometry");
 
+    constexpr bool FILT = MODE != 0;            // the pass over all rows filters against per-query thresholds
+    constexpr bool ONE = MODE == 2;             // the whole call in this launch
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* auxbuf = reinterpret_cast<float*>(smem + 3 * STAGE);                    // [3 stages][2][64]
     unsigned long long* cb = reinterpret_cast<unsigned long long*>(smem + 3 * STAGE + 3 * 2 * 64 * 4);
     unsigned short* cbq = reinterpret_cast<unsigned short*>(cb + HDB_MFMA_CB);
     unsigned int* ctl = reinterpret_cast<unsigned int*>(cbq + HDB_MFMA_CB);       // [0] count, [1..2] flush flags
+    // MODE 2: per-query values every workgroup keeps for the exchange and the finish, BEHIND everything the final sort
+    // overlays (mfma_batch_lds_bytes): [256] thresholds, [256] ||q||^2, [8] flags
+    constexpr int XOFF = (3 * STAGE + 3 * 2 * 64 * 4 + HDB_MFMA_CB * 10 + 64) > (HDB_CAND_CAP * 16 + 2048 * 4 + 64)
+                             ? (3 * STAGE + 3 * 2 * 64 * 4 + HDB_MFMA_CB * 10 + 64) : (HDB_CAND_CAP * 16 + 2048 * 4 + 64);
+    float* xthr = reinterpret_cast<float*>(smem + XOFF);
+    float* xss = xthr + HDB_BATCH_MAXQ;
+    unsigned int* xflag = reinterpret_cast<unsigned int*>(xss + HDB_BATCH_MAXQ);   // [1] aborted (finish), [2] last to leave; [16 .. 80) owners' partial maxima
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    HDB_BSTAMP(0);
     const int rl = lane & (MF - 1);             // row of the A fragment == query of the B fragment
     const int h = lane / MF;                    // which 8-element k-chunk of the step (0..CPS-1)
 
@@ -159,6 +235,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
     int ql[QT];
     Vec Bq[QT][KS];
     float thr_l[QT], qinv_l[QT], qsq_l[QT];
+    if constexpr (!ONE) {
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
         const int q = qw0 + qt * MF + rl;
@@ -182,20 +259,104 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
             if (METRIC == 2) qsq_l[qt] = qsq[q];
         }
     }
+    } else {
+        // ---- MODE 2: query preparation by the wave that multiplies with them (hdb_qprep_kernel, hdb_q16_scale) ----
+        // The sum of squares is accumulated exactly as the prep kernel does it (lane e, e + 64, ... by fma, then the xor
+        // butterfly), so 1/||q||, ||q||^2 and the NaN flag are bit-identical with the multi-kernel pipeline; the maximum
+        // (the fp16 scale) does not depend on the order.  Lane (rl, h) keeps the values of query qt * MF + rl.
+        const float* Qf = static_cast<const float*>(f.Qraw);
+        float ss_l[QT], amax_l[QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const int q = qw0 + qt * MF + rl;
+            q_ok[qt] = q < nq_end;
+            ql[qt] = q - a.q0;
+            ss_l[qt] = 0.f; amax_l[qt] = 0.f;
+        }
+        constexpr int QPL = (D + 63) / 64;
+        constexpr int QB = QPW >= 32 ? 16 : 8;                // queries in flight per step
+        if (wave_active) {
+#pragma unroll 1
+            for (int qi0 = 0; qi0 < QPW; qi0 += QB) {
+                float xs[QB][QPL];
+#pragma unroll
+                for (int j = 0; j < QB; ++j) {
+                    const int q = qw0 + qi0 + j;
+                    const float* qv = Qf + (int64_t)(q < nq_end ? q : nq_end - 1) * D;
+#pragma unroll
+                    for (int u = 0; u < QPL; ++u) { const int e = lane + 64 * u; xs[j][u] = e < D ? qv[e] : 0.f; }
+                }
+#pragma unroll
+                for (int j = 0; j < QB; ++j) {
+                    float ss = 0.f, am = 0.f;
+#pragma unroll
+                    for (int u = 0; u < QPL; ++u) { ss = fmaf(xs[j][u], xs[j][u], ss); am = fmaxf(am, fabsf(xs[j][u])); }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) { ss += __shfl_xor(ss, o, 64); am = fmaxf(am, __shfl_xor(am, o, 64)); }
+                    const int qi = qi0 + j;
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt)
+                        if (qi == qt * MF + rl) { ss_l[qt] = ss; amax_l[qt] = am; }
+                }
+            }
+        }
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            const int q = qw0 + qt * MF + rl;
+            const int qq = q_ok[qt] ? q : (nq_end - 1);
+            float scale = 1.f;
+            if constexpr (ES == 2) scale = hdb_q16_scale(amax_l[qt]);
+            if (wave_active) {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    if constexpr (ES == 2) {
+                        const float4* src = reinterpret_cast<const float4*>(Qf + (int64_t)qq * D + (CPS * s + h) * 8);
+                        const float4 x0 = src[0], x1 = src[1];
+                        Vec v;
+                        v[0] = (_Float16)(x0.x * scale); v[1] = (_Float16)(x0.y * scale); v[2] = (_Float16)(x0.z * scale); v[3] = (_Float16)(x0.w * scale);
+                        v[4] = (_Float16)(x1.x * scale); v[5] = (_Float16)(x1.y * scale); v[6] = (_Float16)(x1.z * scale); v[7] = (_Float16)(x1.w * scale);
+                        if (!q_ok[qt]) v = Vec{0, 0, 0, 0, 0, 0, 0, 0};
+                        Bq[qt][s] = v;
+                    } else {
+                        const float4 x0 = *reinterpret_cast<const float4*>(Qf + (int64_t)qq * D + (CPS * s + h) * 4);
+                        Vec v = {x0.x, x0.y, x0.z, x0.w};
+                        if (!q_ok[qt]) v = Vec{0.f, 0.f, 0.f, 0.f};
+                        Bq[qt][s] = v;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) { if constexpr (ES == 2) Bq[qt][s] = Vec{0, 0, 0, 0, 0, 0, 0, 0}; else Bq[qt][s] = Vec{0.f, 0.f, 0.f, 0.f}; }
+            }
+            thr_l[qt] = 0.f; qinv_l[qt] = 1.f; qsq_l[qt] = 0.f;
+            if (q_ok[qt]) {
+                const float ss = ss_l[qt];
+                const float qs = 1.f / scale;                                      // a power of two: exact
+                const float qi = (ss == 0.f) ? 1.0f : 1.0f / sqrtf(ss);
+                qinv_l[qt] = METRIC == 1 ? qi * qs : qs;
+                if (METRIC == 2) qsq_l[qt] = ss;
+                if (h == 0) xss[ql[qt]] = ss;                                       // for the finish (NaN flag, euclidean re-score)
+            }
+        }
+        if (tid < 8) xflag[tid] = 0u;
+    }
     if (tid < 4) ctl[tid] = 0;
 
     // ---- roles ----------------------------------------------------------------------------------------
     // Waves 0-3 ("A") and 4-7 ("B") are the two waves of each SIMD.  B runs its threshold epilogue one tile
     // late so that the two waves of a SIMD do not reach MFMA phase, epilogue and barrier in lock-step.
     const bool grpB = w >= 4;
+    HDB_BSTAMP(1);
     // B also stages every tile (see the note on staging roles at the top of this file); with up to 4*MF*QT queries in a
     // pass the B waves have no queries and do nothing else.
 
     // loop-invariant scalars, read once (keeps kernel-argument loads out of the tile loop)
     const char* const Vb = reinterpret_cast<const char*>(a.V);
     const int64_t n_rows = a.n;
-    const int64_t ntiles = a.ntiles;
-    const int64_t tstride = a.tile_stride;                      // 1 = dense pass, > 1 = strided row sample
+    int64_t ntiles = ONE ? f.s_tiles : a.ntiles;                // tiles of the current pass (MODE 2: the sample first)
+    int64_t tstride = ONE ? f.s_stride : a.tile_stride;         // 1 = dense pass, > 1 = strided row sample
+    uint32_t* const tile_ctr = ONE ? (a.tile_ctr ? f.ctl + HDB_BATCH_CTL_TILE : nullptr) : a.tile_ctr;   // MODE 2: a.tile_ctr != nullptr = "hand tiles out dynamically"
+    uint32_t* const gcnt = ONE ? f.ctl + HDB_BATCH_CTL_CNT : a.cnt;      // candidates appended per query
     const int64_t gstep = gridDim.x;
 
     // Stage tile number t (global tile index) into ring slot st: waves 4-7 issue PPL LDS-DMA pieces of 1 KiB each
@@ -234,12 +395,34 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
     const unsigned int seg_cbq = (unsigned int)(uintptr_t)HDB_LDS_PTR(cbq) + (unsigned int)w * HDB_MFMA_SEG * 2u;
     auto flush = [&]() {                             // this wave's segment -> a.cand, then empty
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        for (int e = lane; e < wcnt; e += 64) {
-            unsigned long long ent; unsigned int qe;
-            asm volatile("ds_read_b64 %0, %2\n\tds_read_u16 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(ent), "=&v"(qe) : "v"(seg_cb + (unsigned int)e * 8u), "v"(seg_cbq + (unsigned int)e * 2u) : "memory");
-            const unsigned int pos = atomicAdd(&a.cnt[qe], 1u);
-            if (pos < a.cap) a.cand[(int64_t)qe * a.cap + pos] = ent;
+        // One atomic per DISTINCT query among the 64 entries of a step (its first lane adds the group's size and hands the
+        // base to the others): an atomic per entry put 64 returning atomics on 8-32 addresses into one wave-instruction, which
+        // the memory side serialises per address -- 10-38 us per flush while the other workgroups still stream
+        // (profiles/r3_batch1_timeline.txt: N=1.25M, 8 queries, pass done -> arrived).
+        for (int e0 = 0; e0 < wcnt; e0 += 64) {
+            const int e = e0 + lane;
+            const bool live = e < wcnt;
+            unsigned long long ent = 0ull; unsigned int qe = 0xFFFFu;
+            if (live) asm volatile("ds_read_b64 %0, %2\n\tds_read_u16 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                                   : "=&v"(ent), "=&v"(qe) : "v"(seg_cb + (unsigned int)e * 8u), "v"(seg_cbq + (unsigned int)e * 2u) : "memory");
+            unsigned long long todo = __ballot(live);
+            int leader = lane; unsigned int rank = 0u, gsize = 0u;
+            while (todo) {
+                const int first = (int)__ffsll((long long)todo) - 1;
+                const unsigned int fq = (unsigned int)__builtin_amdgcn_readlane((int)qe, first);
+                const unsigned long long grp = __ballot(live && qe == fq);
+                if (live && qe == fq) {
+                    leader = first;
+                    rank = (unsigned int)__popcll(grp & ((1ull << lane) - 1ull));
+                    gsize = (unsigned int)__popcll(grp);
+                }
+                todo &= ~grp;
+            }
+            unsigned int base = 0u;
+            if (live && leader == lane) base = atomicAdd(&gcnt[qe], gsize);
+            base = (unsigned int)__shfl((int)base, leader, 64);
+            const unsigned int pos = base + rank;
+            if (live && pos < a.cap) a.cand[(int64_t)qe * a.cap + pos] = ent;
         }
         wcnt = 0;
     };
@@ -259,13 +442,16 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
     // d=512 (5 M) 0.775 -> 0.764, d=384 1.120 -> 1.106; but d=128 401 -> 438 us, d=256 (5 M) 394 -> 404, d=384 at 2.5 M rows
     // 298 -> 303: short rows (rounds shorter than the hand-over) and short passes (the end of a pass is decided in chunks)
     // lose, so dynamic hand-out needs rows of >= 768 bytes and >= 16 MiB of V per workgroup.
-    const bool dyn = MODE == 1 && a.tile_ctr != nullptr && tstride == 1 && gridDim.y == 1 && !heavy && ROWB >= 768 &&
-                     ntiles * STAGE >= G * (16ll << 20) && !(HDB_MFMA_KNOCKOUT & 2);
     constexpr int LOOK = STAGE >= 48 * 1024 ? 2 : STAGE >= 32 * 1024 ? 3 : STAGE >= 24 * 1024 ? 4 : STAGE >= 16 * 1024 ? 6 : 8;
+    constexpr int64_t CH_ = 2 * LOOK;
+    auto dyn_ok = [&]() { return FILT && tile_ctr != nullptr && tstride == 1 && gridDim.y == 1 && (!heavy || a.dyn_heavy) && ROWB >= 768 &&
+                                 ntiles * STAGE >= G * a.dyn_min_bytes && ntiles >= 4 * CH_ * G && !(HDB_MFMA_KNOCKOUT & 2); };
+    bool dyn = !ONE && dyn_ok();                     // MODE 2: decided when the filter pass begins (the sample is split statically)
     const int64_t CH = 2 * LOOK, dyn0 = G * CH;
     unsigned int* dq = ctl + 4;                      // [2] {first tile - dyn0, length} handed over by wave 3
     const unsigned int dq_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(dq);
     int64_t gp = 0, cidx = 0, coff = 0, cbase = 0, clen = CH, seen = 0;
+    unsigned int req_got = 0u, req_want = 0u, req_slot = 0u; bool req_pending = false;     // wave 3: a chunk request in flight
     auto gen = [&](int64_t& t, int64_t& row0, bool& valid) {     // -> tile and row0 of sequence position gp (and whether it exists)
         if (!dyn) {
             t = bidx + gp * G;
@@ -280,14 +466,24 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
                     clen = (int64_t)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(pr >> 32));
                 }
             }
-            if (w == 3 && coff == clen - LOOK) {                     // request the next chunk LOOK rounds before it is needed
-                const unsigned int want = ntiles - dyn0 - seen > (CH + LOOK) * G ? (unsigned int)CH : (unsigned int)LOOK;
-                unsigned int got = 0u;
-                if (lane == 0) got = __hip_atomic_fetch_add(a.tile_ctr, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                got = (unsigned int)__builtin_amdgcn_readfirstlane((int)got);
-                seen = (int64_t)got + want;
-                const unsigned long long pr = ((unsigned long long)want << 32) | got;
-                if (lane == 0) asm volatile("ds_write_b64 %0, %1" :: "v"(dq_addr + (unsigned int)((cidx + 1) & 1) * 8u), "v"(pr) : "memory");
+            // Wave 3 requests the next chunk LOOK rounds before it is needed and hands the answer over one round later (LOOK >= 2:
+            // a barrier still lies between that LDS write and its readers), so that it never waits for the atomic: with all
+            // eight waves multiplying a wait here would hold every round's barrier up.
+            if (w == 3) {
+                if (req_pending) {
+                    const unsigned int got = (unsigned int)__builtin_amdgcn_readfirstlane((int)req_got);
+                    seen = (int64_t)got + req_want;
+                    const unsigned long long pr = ((unsigned long long)req_want << 32) | got;
+                    if (lane == 0) asm volatile("ds_write_b64 %0, %1" :: "v"(dq_addr + req_slot * 8u), "v"(pr) : "memory");
+                    req_pending = false;
+                }
+                if (coff == clen - LOOK) {
+                    req_want = ntiles - dyn0 - seen > (CH + LOOK) * G ? (unsigned int)CH : (unsigned int)LOOK;
+                    req_got = 0u;
+                    if (lane == 0) req_got = __hip_atomic_fetch_add(tile_ctr, req_want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    req_slot = (unsigned int)((cidx + 1) & 1);
+                    req_pending = true;
+                }
             }
             t = cbase + coff;
             valid = t < ntiles;
@@ -301,11 +497,20 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
         if (grpB) { issue_rows(row0, st); issue_aux(row0, st); }
     };
     int64_t tA, tB, tC = 0, rA, rB, rC = 0; bool vA, vB, vC = false;       // tile / first row / existence of sequence positions i, i+1, i+2
-    gen(tA, rA, vA);
-    gen(tB, rB, vB);
-    const bool had_tiles = vA;
-    if (vA) issue(rA, 0);
-    if (vB) issue(rB, 1);
+    int st_cur = 0;                                  // ring slot of sequence position i
+    bool had_tiles = false;
+    // Start a pass: the first two tiles of its sequence go into slots st_cur and st_cur + 1 (a second pass may start
+    // without a barrier: the slot the previous pass used last is the third one, and every wave is past the barrier of the
+    // round before that).
+    auto begin_pass = [&]() __attribute__((always_inline)) {
+        gp = 0; cidx = 0; coff = 0; cbase = 0; clen = CH; seen = 0; req_pending = false;
+        gen(tA, rA, vA);
+        gen(tB, rB, vB);
+        had_tiles = vA;
+        if (vA) issue(rA, st_cur);
+        if (vB) issue(rB, st_cur == 2 ? 0 : st_cur + 1);
+    };
+    begin_pass();
 
     const unsigned int smem_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(smem);
     // per-lane LDS read address: row rl of a row tile; chunk (CPS*s + h) ^ rx of k-step s is at byte
@@ -325,6 +530,24 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
             else thr_cmp[qt] = thr_l[qt];
         }
     }
+    // MODE 2, phase A: the two largest comparable values this lane has seen, per query tile (NaN counts as -inf)
+    float top0[QT], top1[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) { top0[qt] = -INFINITY; top1[qt] = -INFINITY; }
+    auto sample_update = [&](const Acc (&tv)[QT][RT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int e = 0; e < 4 * NGRP; ++e) {
+                    float v = tv[qt][rt][e];
+                    v = (v != v) ? -INFINITY : v;
+                    const float lo = fminf(top0[qt], v);
+                    top0[qt] = fmaxf(top0[qt], v);
+                    top1[qt] = fmaxf(top1[qt], lo);
+                }
+    };
 
     // Filter, second half: group maxima (v_max3) let the common no-hit case finish in ~25 VALU
     // instructions; survivors go to the workgroup's LDS list.  `tv` holds comparable values (below).
@@ -364,7 +587,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
                                         asm volatile("ds_write_b64 %0, %1\n\tds_write_b16 %2, %3"
                                                      :: "v"(seg_cb + (unsigned int)pos * 8u), "v"(ent), "v"(seg_cbq + (unsigned int)pos * 2u), "v"((unsigned int)ql) : "memory");
                                     } else {         // cannot happen while flushes keep 64 slots free; kept as a safety net
-                                        const unsigned int gpos = atomicAdd(&a.cnt[ql], 1u);
+                                        const unsigned int gpos = atomicAdd(&gcnt[ql], 1u);
                                         if (gpos < a.cap) a.cand[(int64_t)ql * a.cap + gpos] = ent;
                                     }
                                 }
@@ -390,7 +613,13 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
 #endif
     Acc acc[QT][RT];
     int64_t row0_prev = 0;
-    int st_cur = 0;
+    // One pass over the current tile sequence.  ph = 0: MODE 2's sample pass (the epilogue feeds sample_update), otherwise the
+    // pass the MODE names.
+    auto run_pass = [&](auto ph) __attribute__((always_inline)) {
+    constexpr bool SAMPLE = ONE && decltype(ph)::value == 0;
+    auto epi = [&](const Acc (&tv)[QT][RT], int64_t row0) __attribute__((always_inline)) {
+        if constexpr (SAMPLE) sample_update(tv); else filter(tv, row0);
+    };
     for (int64_t i = 0; vA; ++i) {
         if (!vB) hdb_wait_vmcnt<0>();
         else if (grpB) hdb_wait_vmcnt<PPL + NAUX>();         // all but the newest tile's pieces are in
@@ -402,7 +631,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
 
         if (wave_active) {
             const int64_t row0 = rA;
-            if (MODE == 1 && grpB && i > 0) filter(acc, row0_prev);        // deferred epilogue of tile i-1
+            if (FILT && grpB && i > 0) epi(acc, row0_prev);                // deferred epilogue of tile i-1
             // A fragments: LDS reads issued two k-steps ahead of the MFMAs that consume them.  The reads
             // and their counted waits are inline asm so that hipcc cannot sink a read next to its use
             // (it otherwise emits read, lgkmcnt(0), MFMA per step and exposes the LDS latency every step).
@@ -476,7 +705,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
                                 float x;
                                 if (METRIC == 0) x = HAS_BIAS ? fmaf(dot, qinv_l[qt], bj[j]) : dot * qinv_l[qt];   // MODE 0 only without bias
                                 else if (METRIC == 1) {
-                                    if (MODE == 1 && !HAS_BIAS) x = dot * aj[j];
+                                    if (FILT && !HAS_BIAS) x = dot * aj[j];
                                     else x = HAS_BIAS ? fmaf(dot * aj[j], qinv_l[qt], bj[j]) : dot * aj[j] * qinv_l[qt];
                                 } else {
                                     const float d2 = fmaxf(fmaf(-2.f * qinv_l[qt], dot, aj[j] + qsq_l[qt]), 0.f);
@@ -514,26 +743,255 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
                     }
                 }
             } else {
-                if (!grpB) filter(acc, row0);
+                if (!grpB) epi(acc, row0);
                 else row0_prev = row0;
             }
         }
         st_cur = st_cur == 2 ? 0 : st_cur + 1;
         tA = tB; rA = rB; vA = vB; tB = tC; rB = rC; vB = vC;
     }
+    if (FILT && wave_active && grpB && had_tiles) epi(acc, row0_prev);     // the deferred epilogue of the last tile
+    };
+    if constexpr (!ONE) {
+        run_pass(HdbIC<1>());
 #if HDB_MFMA_CLOCK
-    {
-        const unsigned long long clk_c1 = __builtin_amdgcn_s_memtime(), clk_r1 = __builtin_amdgcn_s_memrealtime();
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        if (tid == 0 && blockIdx.y == 0 && blockIdx.x < HDB_CLOCK_WGS) {
-            unsigned long long* o = hdb_clock_buf + 4 * blockIdx.x;
-            o[0] = clk_c0; o[1] = clk_c1; o[2] = clk_r0; o[3] = clk_r1;
+        {
+            const unsigned long long clk_c1 = __builtin_amdgcn_s_memtime(), clk_r1 = __builtin_amdgcn_s_memrealtime();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            if (tid == 0 && blockIdx.y == 0 && blockIdx.x < HDB_CLOCK_WGS) {
+                unsigned long long* o = hdb_clock_buf + 4 * blockIdx.x;
+                o[0] = clk_c0; o[1] = clk_c1; o[2] = clk_r0; o[3] = clk_r1;
+            }
         }
-    }
 #endif
-    if (MODE == 1) {
-        if (wave_active && grpB && had_tiles) filter(acc, row0_prev);
+        if (MODE == 1) flush();
+    } else {
+        // ================= MODE 2: sample pass, exchange, filter pass, finish =================
+        const int nq_all = nq_end - a.q0;                     // queries of this launch (a.q0 == 0 here)
+        hdb_gu64* const thrw = (hdb_gu64*)(reinterpret_cast<char*>(f.ctl) + HDB_BATCH_THRW_BYTE);
+        auto expired = [&](unsigned long long t0) {
+            return (unsigned long long)__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)f.timeout_ticks;
+        };
+        run_pass(HdbIC<0>());                                 // phase A
+        HDB_BSTAMP(2);
+        // the filter pass's first two tiles fly while the thresholds are agreed on
+        ntiles = a.ntiles; tstride = 1; dyn = dyn_ok();
+        begin_pass();
+        // ---- publish: granules [query][workgroup][2 h], [.. + 1] = {epoch, key of this lane's largest, second largest}: ONE 16-byte
+        // store per lane and query tile, the four lanes of a query fill its 64-byte line
+        if (wave_active) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                if (q_ok[qt]) {
+                    const unsigned long long* dst = reinterpret_cast<const unsigned long long*>(f.ctl) + HDB_BATCH_GRAN_BYTE / 8 +
+                                                    ((int64_t)ql[qt] * G + bidx) * 8 + (MF == 16 ? 2 * h : 4 * h);
+                    hdb_st128_sc1(dst, u32x4{hdb_f2key(top0[qt]), f.epoch, hdb_f2key(top1[qt]), f.epoch});
+                    if (MF == 32) hdb_st128_sc1(dst + 2, u32x4{1u, f.epoch, 1u, f.epoch});    // two lane groups per query: four granules stay empty
+                }
+            }
+        }
+        const unsigned long long x_t0 = __builtin_amdgcn_s_memrealtime();
+        HDB_BSTAMP(3);
+        // ---- owners: query q belongs to workgroup q mod G.  The whole workgroup sweeps the G x 8 granules of an owned query
+        // (one wave alone took ~10 us for the 16 KiB: four dependent batches of loads), every wave extracts the 8 largest of
+        // its share, wave 0 the 8-th largest of those 64.
+        {
+            constexpr int M = 8;
+            unsigned int* otop = xflag + 16;                  // [8 waves][M]
+            for (int q = (int)bidx; q < nq_all; q += (int)G) {
+                const int NG = (int)G * 8;
+                bool gave_up = false;
+#if HDB_BATCH_STAMPS
+                unsigned long long attempts = 0ull;
+#endif
+                for (;;) {
+                    bool ok = true;
+#if HDB_BATCH_STAMPS
+                    ++attempts;
+#endif
+                    uint32_t lmax[M];                         // per lane: the M largest of its granules, sorted descending
+#pragma unroll
+                    for (int r = 0; r < M; ++r) lmax[r] = 0u;
+                    const char* srcb = reinterpret_cast<const char*>(f.ctl) + HDB_BATCH_GRAN_BYTE + (int64_t)q * G * 64;
+                    for (int base = tid; base < NG / 2; base += 512 * 2) {       // pairs of granules, two 16-byte loads in flight per thread
+                        const int i0 = base, i1 = base + 512 < NG / 2 ? base + 512 : base;
+                        u32x4 xa, xb;
+                        hdb_ld128x2_sc1(srcb + (int64_t)i0 * 16, srcb + (int64_t)i1 * 16, xa, xb);
+                        auto take = [&](uint32_t key, uint32_t tag, bool dup) __attribute__((always_inline)) {
+                            const bool tagged = tag == f.epoch;
+                            ok &= tagged;
+                            uint32_t v = (tagged && !dup) ? key : 0u;
+#pragma unroll
+                            for (int r = 0; r < M; ++r) { const uint32_t hi = max(lmax[r], v); v = min(lmax[r], v); lmax[r] = hi; }
+                        };
+                        take(xa.x, xa.y, false); take(xa.z, xa.w, false);
+                        take(xb.x, xb.y, i1 == i0); take(xb.z, xb.w, i1 == i0);
+                    }
+#if HDB_BATCH_STAMPS
+                    if (attempts == 1ull) HDB_BSTAMP(11);
+#endif
+                    // workgroup-wide votes through LDS words (xflag[3]: a granule is missing, xflag[4]: time is up)
+                    if (tid == 0) { xflag[3] = 0u; xflag[4] = 0u; }
+                    __syncthreads();
+                    if (!ok) xflag[3] = 1u;
+                    if (!ok && expired(x_t0)) xflag[4] = 1u;
+                    __syncthreads();
+                    if (xflag[3] == 0u) {
+                        HDB_BSTAMP(13);
+#if HDB_BATCH_STAMPS
+                        if (tid == 0 && blockIdx.x < 1024) hdb_batch_stamps[16 * blockIdx.x + 12] = attempts;
+#endif
+#pragma unroll
+                        for (int r = 0; r < M; ++r) {         // M rounds: the wave-wide maximum of the lane heads; its owner pops its head
+                            const uint32_t v = hdb_wave_max_dpp(lmax[0]);
+                            const unsigned long long who = __ballot(lmax[0] == v);
+                            if (lane == (int)__ffsll((long long)who) - 1) {
+#pragma unroll
+                                for (int t = 0; t + 1 < M; ++t) lmax[t] = lmax[t + 1];
+                                lmax[M - 1] = 0u;
+                            }
+                            if (lane == r) otop[w * M + r] = v;
+                        }
+                        break;
+                    }
+                    if (xflag[4] != 0u) { gave_up = true; break; }         // somebody never published
+                    __syncthreads();                                      // (the words are reset after everybody has read them)
+                    __builtin_amdgcn_s_sleep(4);
+                }
+                __syncthreads();
+                HDB_BSTAMP(14);
+                if (w == 0) {
+                    uint32_t v = otop[lane], kth = 0u;
+#pragma unroll
+                    for (int r = 0; r < M; ++r) {
+                        const uint32_t m = hdb_wave_max_dpp(v);
+                        const unsigned long long who = __ballot(v == m);
+                        if (lane == (int)__ffsll((long long)who) - 1) v = 0u;
+                        kth = m;
+                    }
+                    if (kth <= 1u) kth = hdb_f2key(-INFINITY);          // fewer than M sample values exist: no threshold
+                    if (gave_up) {                                       // nothing passes the filter; the host re-runs the call
+                        kth = hdb_f2key(INFINITY);
+                        if (lane == 0) atomicOr(f.ctl + HDB_BATCH_CTL_ABORT, 1u);
+                    }
+                    if (lane == 0) __hip_atomic_store(thrw + q, ((unsigned long long)f.epoch << 32) | kth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+            }
+        }
+        HDB_BSTAMP(4);
+        // ---- everybody: thread t fetches the threshold word of query t
+        if (tid < nq_all) {
+            unsigned long long v;
+            for (;;) {
+                v = __hip_atomic_load(thrw + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((uint32_t)(v >> 32) == f.epoch) break;
+                if (expired(x_t0)) {
+                    v = hdb_f2key(INFINITY);
+                    atomicOr(f.ctl + HDB_BATCH_CTL_ABORT, 1u);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            xthr[tid] = hdb_key2f((uint32_t)v);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) thr_cmp[qt] = q_ok[qt] ? xthr[ql[qt]] : INFINITY;      // already in the comparison domain
+        HDB_BSTAMP(5);
+#if HDB_MFMA_CLOCK
+        const unsigned long long clk_c0b = __builtin_amdgcn_s_memtime(), clk_r0b = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
+        run_pass(HdbIC<1>());                                 // phase B
+#if HDB_MFMA_CLOCK
+        {
+            const unsigned long long clk_c1 = __builtin_amdgcn_s_memtime(), clk_r1 = __builtin_amdgcn_s_memrealtime();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            if (tid == 0 && blockIdx.x < HDB_CLOCK_WGS) {
+                unsigned long long* o = hdb_clock_buf + 4 * blockIdx.x;
+                o[0] = clk_c0b; o[1] = clk_c1; o[2] = clk_r0b; o[3] = clk_r1;
+            }
+        }
+#endif
+        HDB_BSTAMP(6);
         flush();
+        // ---- finish: drain, release, arrive; wait for everybody; owners sort their queries
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(f.ctl + HDB_BATCH_CTL_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            HDB_BSTAMP(7);
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            bool all_in = true;
+            while (__hip_atomic_load(f.ctl + HDB_BATCH_CTL_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)G) {
+                if (expired(t0)) { all_in = false; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (!all_in) atomicOr(f.ctl + HDB_BATCH_CTL_ABORT, 1u);
+            const unsigned int ab = __hip_atomic_load(f.ctl + HDB_BATCH_CTL_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            xflag[1] = (ab != 0u || !all_in) ? 1u : 0u;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        const bool aborted = xflag[1] != 0u;
+        HDB_BSTAMP(8);
+        unsigned long long* fbuf = reinterpret_cast<unsigned long long*>(smem);     // the ring is free now
+        for (int q = (int)bidx; q < nq_all; q += (int)G) {
+            const uint32_t tot0 = __hip_atomic_load(gcnt + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t tot = aborted ? 0u : tot0;
+            const float ssq = xss[q];
+            // euclidean scores come from ||v||^2 + ||q||^2 - 2 v.q, which cancels when v ~ q: candidates closer than 5 % of
+            // ||q||^2 are re-scored from the stored row with the direct difference (hdb_rescore_euclid_kernel, reference :49)
+            auto rescore = [&](unsigned long long* buf, uint32_t nc) {
+                if constexpr (METRIC == 2) {
+                    const float* qv = static_cast<const float*>(f.Qraw) + (int64_t)q * D;
+                    const float close2 = 0.05f * ssq;
+                    const E* Vr = static_cast<const E*>(a.V);
+                    for (uint32_t e = (uint32_t)w; e < nc; e += 8u) {
+                        const unsigned long long ent = buf[e];
+                        const uint32_t row = 0xFFFFFFFFu - (uint32_t)(ent & 0xFFFFFFFFull);
+                        float s = hdb_key2f((uint32_t)(ent >> 32));
+                        const float bb = HAS_BIAS ? a.bias[row] : 0.f;
+                        const float sim = s - bb;
+                        const float dist = 1.f / sim - 1.f;
+                        if (sim > 0.f && dist * dist < close2) {           // wave-uniform: one entry per wave
+                            float accd = 0.f;
+                            for (int kx = lane; kx < D; kx += 64) { const float df = (float)Vr[(int64_t)row * D + kx] - qv[kx]; accd += df * df; }
+#pragma unroll
+                            for (int o = 32; o > 0; o >>= 1) accd += __shfl_xor(accd, o, 64);
+                            s = hdb_canon(1.f / (1.f + sqrtf(accd)) + bb);
+                            if (lane == 0) buf[e] = hdb_pack(s, row);
+                        }
+                    }
+                    __syncthreads();
+                }
+            };
+            hdb_finalize_body(fbuf, a.cand + (int64_t)q * a.cap, tot, q, a.cap, f.k, f.kk, f.row_base, f.idx_out, f.score_out, f.status,
+                              (ssq != ssq) ? 1 : 0, 0, nullptr, 1.f, rescore);
+            __syncthreads();
+        }
+        // ---- leave: the last workgroup out zeroes the control block for the next launch
+        __syncthreads();
+        HDB_BSTAMP(9);
+        if (tid == 0) {
+            const unsigned int left = __hip_atomic_fetch_add(f.ctl + HDB_BATCH_CTL_EXIT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            xflag[2] = left == (unsigned int)G - 1u ? 1u : 0u;
+        }
+        __syncthreads();
+        if (xflag[2]) {
+            if (tid < nq_all) __hip_atomic_store(f.ctl + HDB_BATCH_CTL_CNT + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) {
+                __hip_atomic_store(f.ctl + HDB_BATCH_CTL_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(f.ctl + HDB_BATCH_CTL_EXIT, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(f.ctl + HDB_BATCH_CTL_TILE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(f.ctl + HDB_BATCH_CTL_ABORT, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        HDB_BSTAMP(10);
     }
 }
 
@@ -541,34 +999,48 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
 static size_t mfma_lds_bytes(int stage_bytes) {
     return (size_t)3 * stage_bytes + 3 * 2 * 64 * 4 + (size_t)HDB_MFMA_CB * 8 + (size_t)HDB_MFMA_CB * 2 + 64;
 }
+// MODE 2: the scan's LDS or the final sort's (hdb_finalize_body overlays the ring), whichever is larger, plus the per-query
+// values kept behind both (XOFF in the kernel)
+static size_t mfma_batch_lds_bytes(int stage_bytes) {
+    const size_t scan = mfma_lds_bytes(stage_bytes), fin = (size_t)HDB_CAND_CAP * 16 + 2048 * 4 + 64;
+    return (scan > fin ? scan : fin) + 2 * HDB_BATCH_MAXQ * 4 + 512;
+}
 
 template <typename E, int MF, int QT, int D, int R, int RS, int MODE, int METRIC, bool HAS_BIAS>
-static int launch_one(const ScanArgs& a, const void* q16, const float* aux0, const float* qsq, const float* qscl, int nq_launch, int blocks, hipStream_t st) {
+static int launch_one(const ScanArgs& a, const void* q16, const float* aux0, const float* qsq, const float* qscl, int nq_launch, int blocks, hipStream_t st,
+                      const BatchArgs* f) {
     auto kern = hdb_mfma_kernel<E, MF, QT, D, R, RS, MODE, METRIC, HAS_BIAS>;
-    const size_t lds = mfma_lds_bytes(R * D * (int)sizeof(E));
+    const size_t lds = MODE == 2 ? mfma_batch_lds_bytes(R * D * (int)sizeof(E)) : mfma_lds_bytes(R * D * (int)sizeof(E));
     static unsigned long long attr_done = 0;          // per instantiation, one bit per device
     hipError_t e = hdb_lds_attr_once(reinterpret_cast<const void*>(kern), (int)lds, &attr_done);
     if (e != hipSuccess) return (int)e;
     const dim3 grid(blocks, (nq_launch + (8 / RS) * MF * QT - 1) / ((8 / RS) * MF * QT));
-    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a, (const E*)q16, aux0, qsq, qscl, a.q0 + nq_launch);
+    if (MODE == 2 && (grid.y != 1 || !f || a.q0 != 0)) return (int)hipErrorInvalidValue;
+    BatchArgs fa = BatchArgs();
+    if (f) fa = *f;
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a, (const E*)q16, aux0, qsq, qscl, a.q0 + nq_launch, fa);
     return (int)hipGetLastError();
 }
 
 template <typename E, int MF, int QT, int D, int R, int RS, int MODE>
-static int launch_metric(const ScanArgs& a, const void* q16, const float* sqnorm, const float* qsq, const float* qscl, int nq_launch, int blocks, hipStream_t st) {
+static int launch_metric(const ScanArgs& a, const void* q16, const float* sqnorm, const float* qsq, const float* qscl, int nq_launch, int blocks, hipStream_t st,
+                         const BatchArgs* f) {
     const bool b = a.bias != nullptr;
-    if (a.metric == HDB_DOT) return b ? launch_one<E, MF, QT, D, R, RS, MODE, 0, true>(a, q16, nullptr, qsq, qscl, nq_launch, blocks, st)
-                                      : launch_one<E, MF, QT, D, R, RS, MODE, 0, false>(a, q16, nullptr, qsq, qscl, nq_launch, blocks, st);
-    if (a.metric == HDB_COSINE) return b ? launch_one<E, MF, QT, D, R, RS, MODE, 1, true>(a, q16, a.inv_norm, qsq, qscl, nq_launch, blocks, st)
-                                         : launch_one<E, MF, QT, D, R, RS, MODE, 1, false>(a, q16, a.inv_norm, qsq, qscl, nq_launch, blocks, st);
-    if (a.metric == HDB_EUCLIDEAN) return b ? launch_one<E, MF, QT, D, R, RS, MODE, 2, true>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st)
-                                            : launch_one<E, MF, QT, D, R, RS, MODE, 2, false>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
+    if (a.metric == HDB_DOT) return b ? launch_one<E, MF, QT, D, R, RS, MODE, 0, true>(a, q16, nullptr, qsq, qscl, nq_launch, blocks, st, f)
+                                      : launch_one<E, MF, QT, D, R, RS, MODE, 0, false>(a, q16, nullptr, qsq, qscl, nq_launch, blocks, st, f);
+    if (a.metric == HDB_COSINE) return b ? launch_one<E, MF, QT, D, R, RS, MODE, 1, true>(a, q16, a.inv_norm, qsq, qscl, nq_launch, blocks, st, f)
+                                         : launch_one<E, MF, QT, D, R, RS, MODE, 1, false>(a, q16, a.inv_norm, qsq, qscl, nq_launch, blocks, st, f);
+    if (a.metric == HDB_EUCLIDEAN) return b ? launch_one<E, MF, QT, D, R, RS, MODE, 2, true>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st, f)
+                                            : launch_one<E, MF, QT, D, R, RS, MODE, 2, false>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st, f);
     return (int)hipErrorNotSupported;
 }
 
+// mode 2 (the whole call in one launch) takes BatchArgs; q16 / qsq / qscl are unused there (the kernel prepares the queries)
 template <typename E, int MF, int QT, int D, int R, int RS = 1>
-static int launch_mode(const ScanArgs& a, int mode, const void* q16, const float* sqnorm, const float* qsq, const float* qscl, int nq_launch, int blocks, hipStream_t st) {
-    if (mode == 0) return launch_metric<E, MF, QT, D, R, RS, 0>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
-    return launch_metric<E, MF, QT, D, R, RS, 1>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
+static int launch_mode(const ScanArgs& a, int mode, const void* q16, const float* sqnorm, const float* qsq, const float* qscl, int nq_launch, int blocks, hipStream_t st,
+                       const BatchArgs* f = nullptr) {
+    if (mode == 0) return launch_metric<E, MF, QT, D, R, RS, 0>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st, nullptr);
+    if (mode == 2) return launch_metric<E, MF, QT, D, R, RS, 2>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st, f);
+    return launch_metric<E, MF, QT, D, R, RS, 1>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st, nullptr);
 }
 

@@ -4,14 +4,14 @@
 #include "hdb_mfma_kernel.h"
 
 extern "C" int hdb_launch_mfma_scan_f16_wide(const ScanArgs* args, int mode, int nq_launch, const void* q16, const float* sqnorm,
-                                             const float* qsq, const float* qscl, int blocks, void* stream) {
+                                             const float* qsq, const float* qscl, int blocks, void* stream, const BatchArgs* f) {
     const ScanArgs& a = *args;
     hipStream_t st = (hipStream_t)stream;
     switch (a.d) {
-        case 896: return launch_mode<_Float16, 16, 1, 896, 16>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
-        case 1152: return launch_mode<_Float16, 16, 1, 1152, 16>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
-        case 1280: return launch_mode<_Float16, 16, 1, 1280, 16>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
-        case 1408: return launch_mode<_Float16, 16, 1, 1408, 16>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
+        case 896: return launch_mode<_Float16, 16, 1, 896, 16>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st, f);
+        case 1152: return launch_mode<_Float16, 16, 1, 1152, 16>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st, f);
+        case 1280: return launch_mode<_Float16, 16, 1, 1280, 16>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st, f);
+        case 1408: return launch_mode<_Float16, 16, 1, 1408, 16>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st, f);
         default: return (int)hipErrorNotSupported;
     }
 }

@@ -1048,7 +1048,7 @@ def test_fp64_and_query_dtype_promotion(ranking, orc):
     assert np.allclose(sc, osc) and set(sc) == set(osc)
 
 
-def test_full_size_q256_mfma_equals_single_query_scan(big_fp16):
+def test_full_size_q256_mfma_equals_single_query_scan(big_fp16, orc):
     """Config 3 at full size: the 256-query MFMA pass against the single-query row scan, query by query."""
     import torch
     from hyperdb._native import METRIC_IDS
@@ -1057,7 +1057,11 @@ def test_full_size_q256_mfma_equals_single_query_scan(big_fp16):
     Q = bench.make_queries(256, 384, torch.float16, V.device)
     mid = METRIC_IDS["dot_product"]
     bi, bs, st = ix.topk_device(Q, 100, mid)
-    assert ix.stat("mfma") == 1 and int(st.abs().sum().item()) == 0
+    assert ix.stat("mfma") == 1 and ix.stat("fused") == 2 and int(st.abs().sum().item()) == 0      # ONE launch for the batch
+    ix.set_option("use_fused", 0)                      # the five-kernel pipeline: same rows, same scores, bit for bit
+    ui, us, ust = ix.topk_device(Q, 100, mid)
+    ix.set_option("use_fused", 1)
+    assert ix.stat("fused") == 0 and int(ust.abs().sum().item()) == 0 and torch.equal(bi, ui) and torch.equal(bs, us)
     ix.set_option("use_mfma", 0)
     try:
         for qi in (0, 100, 255):
@@ -1067,6 +1071,19 @@ def test_full_size_q256_mfma_equals_single_query_scan(big_fp16):
             assert torch.allclose(ss[0], bs[qi], rtol=2e-6, atol=2e-5)
     finally:
         ix.set_option("use_mfma", 1)
+    # every one of the 256 x 100 returned rows re-scored in float64 from the stored row (as config 5 does) ...
+    Qh = Q.float().cpu().numpy().astype(np.float64)
+    bi_h, bs_h = bi.cpu().numpy(), bs.cpu().numpy().astype(np.float64)
+    for q0 in range(0, 256, 32):
+        rows = V[bi[q0:q0 + 32].reshape(-1)].float().cpu().numpy().astype(np.float64).reshape(32, 100, 384)
+        ex = np.einsum("qkd,qd->qk", rows, Qh[q0:q0 + 32])
+        got = bs_h[q0:q0 + 32]
+        assert np.all(np.abs(ex - got) <= 1e-3 * np.maximum(1.0, np.abs(ex))), q0
+        assert np.all(np.diff(got, axis=1) <= 0)
+    assert all(np.unique(bi_h[q]).size == 100 for q in range(256))
+    # ... and an independent omission check over the whole row range for the first, a middle and the last query
+    for qi in (0, 127, 255):
+        _assert_nothing_left_out(orc, V, Q[qi].float().cpu().numpy(), "dot_product", bi_h[qi], bs_h[qi], 1e-3)
 
 
 def test_sample_does_not_alias_with_periodic_data(orc):
@@ -1336,7 +1353,8 @@ def test_single_launch_pipeline_equals_multi_kernel_and_oracle(orc, n, d):
                     ix.set_option("use_fused", 1)
                     fi, fs, fst = ix.topk_device(Q[:nq], k, mid)
                     single = nq <= (4 if d <= 768 else 2)      # beyond d = 768 the query fragments live in LDS: two queries
-                    assert ix.stat("fused") == int(single) and ix.stat("path") == 1 and int(fst.abs().sum().item()) == 0, (metric, setup, nq, k)
+                    # (three and four queries on the wide rows take the batched single launch, stat 2: hdb_mfma_kernel.h MODE 2)
+                    assert ix.stat("fused") == (1 if single else 2) and ix.stat("path") == 1 and int(fst.abs().sum().item()) == 0, (metric, setup, nq, k)
                     ix.set_option("use_fused", 0)
                     ui, us, ust = ix.topk_device(Q[:nq], k, mid)
                     assert ix.stat("fused") == 0
@@ -1348,10 +1366,10 @@ def test_single_launch_pipeline_equals_multi_kernel_and_oracle(orc, n, d):
             assert ix.stat("fused") == 1
             for qi in range(2):
                 orc.check_topk(idx[qi], sc[qi], V, Q[qi], metric, 100, tol=1e-3)
-        # k > 128, five queries, euclidean: not the fused kernel's business
+        # k > 128: the multi-kernel pipeline; five queries, euclidean: the batched single launch (stat 2)
         ix.topk_device(Q[:1], 200, METRIC_IDS["dot_product"]); assert ix.stat("fused") == 0
-        ix.topk_device(np.concatenate([Q, Q[:1]]), 10, METRIC_IDS["dot_product"]); assert ix.stat("fused") == 0
-        ix.topk_device(Q[:1], 10, METRIC_IDS["euclidean_metric"]); assert ix.stat("fused") == 0
+        ix.topk_device(np.concatenate([Q, Q[:1]]), 10, METRIC_IDS["dot_product"]); assert ix.stat("fused") == 2
+        ix.topk_device(Q[:1], 10, METRIC_IDS["euclidean_metric"]); assert ix.stat("fused") == 2
     finally:
         ix.close()
 
@@ -1557,5 +1575,128 @@ def test_single_launch_pipeline_float32(orc, n, d):
                 assert ix.stat("fused") == 1
                 orc.check_topk(idx[0], sc[0], V, Q[qi], metric, 100, tol=1e-5)
         ix.topk_device(Q[:3], 10, METRIC_IDS["dot_product"]); assert ix.stat("fused") == 0      # three float32 queries: five-kernel pipeline
+    finally:
+        ix.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# 12. the single-launch BATCHED pipeline (hdb_mfma_kernel.h, MODE 2): 5-256 dot / cosine queries, 1-256 euclidean
+#     ones, fp16 and float32 matrices -- one launch per <= 256 queries
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt,n,d,nqs", [(np.float16, 200_003, 384, (5, 16, 100, 256, 300)), (np.float16, 60_017, 768, (1, 7, 64, 130)),
+                                         (np.float16, 30_000, 128, (40, 256)), (np.float16, 90_001, 512, (33, 200)),
+                                         (np.float16, 50_000, 1536, (3, 32)), (np.float16, 8_193, 384, (9,)),
+                                         (np.float16, 1_300_001, 384, (17,)), (np.float32, 120_000, 384, (5, 64, 130)),
+                                         (np.float32, 70_000, 768, (8, 128))])
+def test_batched_single_launch_equals_multi_kernel_and_oracle(orc, dt, n, d, nqs):
+    """Every call shape the batched single launch takes -- query counts on both sides of a launch's capacity (chunks of 128 /
+    256), dot / cosine / euclidean, k = 1 .. 128, bias, row mask, ragged last tile, grids smaller than the CU count, a
+    float32 query far outside the fp16 range -- returns exactly what the five-kernel pipeline returns (and, for dot /
+    cosine, the on-device exact selection), bit for bit; one query per shape is checked against the oracle's float64 scores."""
+    import torch
+    from hyperdb._native import GpuIndex, METRIC_IDS
+    g = torch.Generator(device="cuda").manual_seed(n + d)
+    V = torch.randn((n, d), generator=g, device="cuda").to(torch.float16 if dt == np.float16 else torch.float32)
+    V[n - 1] = V[7]                                        # duplicate rows across the matrix ends: tie -> lower row first
+    ix = GpuIndex(V)
+    try:
+        bias = (torch.rand(n, generator=g, device="cuda") * 0.2).float()
+        mask = (torch.rand(n, generator=g, device="cuda") < 0.3).to(torch.uint8)
+        for nq in nqs:
+            Q = torch.randn((nq, d), generator=g, device="cuda").float()
+            Q[0] = V[n // 3].float()                       # an exact duplicate of a stored row (euclidean: re-scored directly)
+            if nq > 2:
+                Q[2] = Q[2] * 37.5                         # a genuinely float32 query: norm sums must round alike in both pipelines
+            for metric in ("cosine_similarity", "dot_product", "euclidean_metric"):
+                if metric != "euclidean_metric" and nq <= (4 if d <= 768 else 2) and dt == np.float16:
+                    continue                               # hdb_mfma_fused_kernel's calls
+                if dt == np.float32 and nq < 5:
+                    continue                               # the VALU pipelines' calls
+                mid = METRIC_IDS[metric]
+                for setup in ("plain", "bias", "mask+bias"):
+                    ix.set_bias(bias if "bias" in setup else None)
+                    ix.set_row_mask(mask if "mask" in setup else None)
+                    for k in (100, 1, 128):
+                        ix.set_option("use_fused", 1)
+                        fi, fs, fst = ix.topk_device(Q, k, mid)
+                        assert ix.stat("fused") == 2 and ix.stat("path") == 1 and ix.stat("mfma") == 1, (nq, metric, setup, k)
+                        assert int(fst.abs().sum().item()) == 0, (nq, metric, setup, k)
+                        ix.set_option("use_fused", 0)
+                        ui, us, ust = ix.topk_device(Q, k, mid)
+                        assert ix.stat("fused") == 0 and int(ust.abs().sum().item()) == 0
+                        ix.set_option("use_fused", 1)
+                        assert torch.equal(fi, ui) and torch.equal(fs, us), (nq, metric, setup, k)
+                        if metric != "euclidean_metric" and k == 100 and nq <= 64:      # (euclidean: the exact selection ranks before the re-score)
+                            ei, es, _ = ix.topk_device(Q, k, mid, exact=True)
+                            assert torch.equal(fi, ei) and torch.equal(fs, es), (nq, metric, setup, k)
+                ix.set_bias(None); ix.set_row_mask(None)
+                idx, sc = ix.topk(Q[:min(nq, 3)], 100, mid)
+                Vh = V.cpu().numpy()
+                tol = 1e-3 if dt == np.float16 else 1e-5
+                for qi in range(min(nq, 3)):
+                    if qi == 2 and metric == "euclidean_metric":
+                        continue                           # |q| >> |v|: 1/(1+dist) is ill-conditioned in float32 (test_mfma_query_magnitude)
+                    orc.check_topk(idx[qi], sc[qi], Vh, Q[qi].cpu().numpy(), metric, 100, tol=tol)
+                if metric == "euclidean_metric":
+                    assert idx[0][0] == n // 3 and abs(sc[0][0] - 1.0) < 1e-6, "an exact duplicate must score exactly 1"
+    finally:
+        ix.close()
+
+
+def test_batched_single_launch_failure_paths(orc):
+    """What must come back through the exact selection: a NaN query (status bit), massive ties that overflow the candidate
+    lists, a row mask that leaves fewer than 8 sampled rows (threshold -inf), and an exchange that gives up (spin timeout
+    forced to its floor) -- the host entry still returns the right rows, and the next call is clean."""
+    import torch
+    from hyperdb._native import GpuIndex, METRIC_IDS, Q_NAN
+    rng = np.random.default_rng(77)
+    base = rng.standard_normal((40, 384)).astype(np.float32).astype(np.float16)
+    V = np.tile(base, (1500, 1))                           # 60k rows, every score repeated 1500 times
+    Q = rng.standard_normal((9, 384)).astype(np.float16).astype(np.float32)
+    ix = GpuIndex(V)
+    try:
+        mid = METRIC_IDS["dot_product"]
+        ix.topk_device(Q, 100, mid)
+        assert ix.stat("fused") == 2
+        idx, sc = ix.topk(Q, 100, mid)                     # hdb_topk_host re-runs overflowing lists through the exact path
+        for qi in (0, 8):
+            ex = orc.exact_scores(V, Q[qi], "dot_product")
+            want = np.nonzero(np.isclose(ex, ex.max(), rtol=1e-6))[0][:100]
+            assert np.array_equal(idx[qi], want) and np.allclose(sc[qi], ex.max(), rtol=1e-3)
+    finally:
+        ix.close()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    n = 300_000
+    V2 = torch.randn((n, 384), generator=g, device="cuda").to(torch.float16)
+    Q2 = torch.randn((20, 384), generator=g, device="cuda").float()
+    ix = GpuIndex(V2)
+    try:
+        mid = METRIC_IDS["cosine_similarity"]
+        Qn = Q2.clone(); Qn[5, 17] = float("nan")
+        _, _, st = ix.topk_device(Qn, 10, mid)
+        assert ix.stat("fused") == 2 and (int(st[5].item()) & Q_NAN) and not any(int(st[q].item()) & Q_NAN for q in range(20) if q != 5)
+        # fewer than 8 unmasked rows in the sample: the threshold is -inf, every unmasked row is a candidate
+        ix.set_row_mask((torch.rand(n, generator=g, device="cuda") < 0.004).to(torch.uint8))
+        fi, fs, st = ix.topk_device(Q2, 50, mid)
+        ei, es, _ = ix.topk_device(Q2, 50, mid, exact=True)
+        for q in range(20):
+            if int(st[q].item()) == 0:
+                assert torch.equal(fi[q], ei[q]) and torch.equal(fs[q], es[q]), q
+        hi, hs = ix.topk(Q2, 50, mid)
+        assert np.array_equal(hi, ei.cpu().numpy()) and np.array_equal(hs, es.cpu().numpy())
+        ix.set_row_mask(None)
+        # forced timeout: statuses tell, the host entry falls back, the next call is clean
+        ei, es, _ = ix.topk_device(Q2, 50, mid, exact=True)
+        ix.set_option("fused_timeout_us", 1)
+        fi, fs, st = ix.topk_device(Q2, 50, mid)
+        assert ix.stat("fused") == 2
+        for q in range(20):
+            if int(st[q].item()) == 0:
+                assert torch.equal(fi[q], ei[q]) and torch.equal(fs[q], es[q]), q
+        hi, hs = ix.topk(Q2, 50, mid)
+        assert np.array_equal(hi, ei.cpu().numpy()) and np.array_equal(hs, es.cpu().numpy())
+        ix.set_option("fused_timeout_us", 2000)
+        fi, fs, st = ix.topk_device(Q2, 50, mid)
+        assert int(st.abs().sum().item()) == 0 and torch.equal(fi, ei) and torch.equal(fs, es)
     finally:
         ix.close()

@@ -61,12 +61,12 @@ print(json.dumps({"rc": rc, "warm_calls": calls, "kernel_us_hip_events": ns / l 
 def build():
     os.makedirs(OUT, exist_ok=True)
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    objs = [os.path.join(CSRC, 'obj', f'{n}.o') for n in ('hdb_scan', 'hdb_select', 'hdb_mfma_f32', 'hdb_mfma_qt2', 'hdb_mfma_wide', 'hdb_mfma_fused', 'hdb_mfma_fused_wide', 'hdb_sort', 'hdb_rows', 'hdb_api')]
+    objs = [os.path.join(CSRC, 'obj', f'{n}.o') for n in ('hdb_mfma', 'hdb_mfma_f32', 'hdb_mfma_f32b', 'hdb_mfma_qt2', 'hdb_mfma_wide', 'hdb_mfma_mid', 'hdb_mfma_narrow', 'hdb_mfma_1k', 'hdb_mfma_fused', 'hdb_mfma_fused_wide', 'hdb_scan', 'hdb_select', 'hdb_sort', 'hdb_rows', 'hdb_api')]
     procs = []
     for v in VARIANTS:
         o = os.path.join(OUT, f'mfma_{v}.o')
         procs.append(subprocess.Popen([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-pass-failed', '-DHDB_MFMA_CLOCK=1',
-                                       f'-DHDB_MFMA_KNOCKOUT={v}', '-c', os.path.join(CSRC, 'hdb_mfma.hip'), '-o', o]))
+                                       f'-DHDB_MFMA_KNOCKOUT={v}', '-c', os.path.join(CSRC, 'hdb_mfma_d384.hip'), '-o', o]))
     for p in procs:
         if p.wait(): raise SystemExit('hipcc failed')
     for v in VARIANTS:

@@ -42,12 +42,12 @@ print(json.dumps({"parity_ok": bool(ok), "kernel_us": times}), flush=True)
 def build(variants):
     os.makedirs(OUT, exist_ok=True)
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    objs = [os.path.join(CSRC, 'obj', f'{n}.o') for n in ('hdb_scan', 'hdb_select', 'hdb_mfma_f32', 'hdb_mfma_qt2', 'hdb_mfma_wide', 'hdb_mfma_fused', 'hdb_mfma_fused_wide', 'hdb_sort', 'hdb_rows', 'hdb_api')]
+    objs = [os.path.join(CSRC, 'obj', f'{n}.o') for n in ('hdb_mfma', 'hdb_mfma_f32', 'hdb_mfma_f32b', 'hdb_mfma_qt2', 'hdb_mfma_wide', 'hdb_mfma_mid', 'hdb_mfma_narrow', 'hdb_mfma_1k', 'hdb_mfma_fused', 'hdb_mfma_fused_wide', 'hdb_scan', 'hdb_select', 'hdb_sort', 'hdb_rows', 'hdb_api')]
     procs = []
     for v in variants:
         o = os.path.join(OUT, f'mfma_{v}.o')
         procs.append(subprocess.Popen([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-pass-failed',
-                                       f'-DHDB_MFMA_EXP={v}', '-c', os.path.join(CSRC, 'hdb_mfma.hip'), '-o', o]))
+                                       f'-DHDB_MFMA_EXP={v}', '-c', os.path.join(CSRC, 'hdb_mfma_d384.hip'), '-o', o]))
         if len(procs) % 4 == 0:
             for p in procs[-4:]:
                 if p.wait(): raise SystemExit('hipcc failed')
