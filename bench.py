@@ -25,6 +25,11 @@ One JSON line is printed by rank 0.  Besides the contract fields it carries
   cpu_baseline  -- the numpy restatement of the reference (oracle/), timed on this host on a bounded
                    row prefix and scaled linearly to N (rank 0, --gpus 1 only).
   batched       -- config 3 of BASELINE.json (Q=256 dot-product) measured in the same run.
+  api           -- (--gpus 1) p50 of the SAME query stream through the drop-in entry points, numpy queries on the host:
+                   ranking.hyperDB_ranking_algorithm_sort(handle, q, top_k) and HyperDB.query(q, top_k) (reference
+                   ranking_algorithm.py:149, hyperdb.py:1584), beside the p50 of the kernel path the headline times.
+  exchange_alt  -- (--gpus N > 1) both transports of the per-query exchange are timed in the same run: `value` uses the one
+                   named in config.exchange (chosen by a calibration inside the warm-up), exchange_alt reports the other.
 """
 import argparse
 import json
@@ -143,6 +148,8 @@ def extra_leg(name, device):
         n, d, dt, elem, q, metric, steps, bias = 1_000_000, 384, torch.float32, 4, 1, "cosine_similarity", 200, False
     elif name == "c5":    # N=10M d=768 fp16 euclidean + time-decay re-rank, batch-Q=64
         n, d, dt, elem, q, metric, steps, bias = 10_000_000, 768, torch.float16, 2, 64, "euclidean_metric", 10, True
+    elif name == "hamming":   # supplementary: the headline matrix through hamming_distance
+        n, d, dt, elem, q, metric, steps, bias = 10_000_000, 384, torch.float16, 2, 1, "hamming_distance", 200, False
     else:
         raise SystemExit(f"unknown extra config {name}")
     V, lo, hi = make_shard(n, d, dt, 0, 1, device)
@@ -168,9 +175,11 @@ def extra_leg(name, device):
     ns, nl = ix.stat("scan_time_ns"), ix.stat("scan_launches")
     kern_s = ns * 1e-9 / max(nl, 1)
     alg = n * d * elem
+    if metric == "hamming_distance":
+        alg = n * ((d + 31) // 32) * 4              # packed sign bits, word-major: what the scan reads (one-time pack excluded)
     out = {"config": name, "workload": f"N={n} d={d} {'fp32' if elem == 4 else 'fp16'} Q={q} {metric}{' + recency bias' if bias else ''} top-100",
            "qps": q * steps / el, "ms_per_call": 1e3 * el / steps, "p50_ms": 1e3 * float(np.median(lat)),
-           "kernel_us": kern_s * 1e6, "mfma_path": bool(ix.stat("mfma")),
+           "kernel_us": kern_s * 1e6, "mfma_path": bool(ix.stat("mfma")), "single_launch": bool(ix.stat("fused")),
            "roofline": {"bound": "hbm", "achieved": alg / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": alg / kern_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg}}
     ix.close()
@@ -207,8 +216,19 @@ def main():
     elem = 2 if args.dtype == "fp16" else 4
     V, lo, hi = make_shard(args.n, args.d, tdtype, rank, world, device)
     local = GpuIndex(V, device=device, row_base=lo)
-    sharded = ShardedIndex(local, n_total=args.n, group=(dist.group.WORLD if dist else None),
-                           force_exchange=os.environ.get("HDB_FORCE_DIST") == "1")
+    grp = dist.group.WORLD if dist else None
+    force = os.environ.get("HDB_FORCE_DIST") == "1"
+    sharded = ShardedIndex(local, n_total=args.n, group=grp, force_exchange=force)
+    # Both transports of the per-query exchange (N > 1): the RCCL all-gather of the packed device records (+ merge kernel) and,
+    # where every rank sits on this node, the shared-memory swap of the host records.  A calibration inside the warm-up picks
+    # the one `value` is timed with (unless HDB_EXCHANGE names one); the other is timed afterwards as exchange_alt.
+    alt = None
+    if world > 1 and not os.environ.get("HDB_EXCHANGE"):
+        other = "collective" if sharded._hx is not None else "host"
+        try:
+            alt = ShardedIndex(local, n_total=args.n, group=grp, force_exchange=force, exchange=other)
+        except Exception:
+            alt = None
     # queries: fp16/fp32 values as the config says, staged in the C ABI's query type (float32: exact for fp16)
     Q = make_queries(max(args.steps + args.warmup, 1), args.d, tdtype, device).to(torch.float32)
     mid = METRIC_IDS[args.metric]
@@ -219,9 +239,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def kind_of(sh):
+        return ("none" if world == 1 else
+                "shared-memory swap of the ranks' host records + host merge, once per query" if sh._hx is not None
+                else "1 RCCL all-gather of packed top-k per query + merge kernel")
+
+    def p50_of(sh, count):
+        ts = np.empty(count)
+        for j in range(count):
+            t0 = time.perf_counter()
+            sh.query(Q[j % Q.shape[0]:j % Q.shape[0] + 1], args.k, mid)
+            ts[j] = time.perf_counter() - t0
+        t = torch.tensor([float(np.median(ts))], dtype=torch.float64, device=device if not (dist and dist.get_backend() == "gloo") else "cpu")
+        if dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     # ---------------- single-query leg: the headline metric --------------------------------------
     for i in range(args.warmup):
         sharded.query(Q[i:i + 1], args.k, mid)
+    calib = None
+    if alt is not None:                                  # calibration (untimed): every rank takes the same decision
+        for i in range(min(args.warmup, 5)):
+            alt.query(Q[i:i + 1], args.k, mid)
+        calib = {kind_of(sharded): p50_of(sharded, 30), kind_of(alt): p50_of(alt, 30)}
+        if calib[kind_of(alt)] < calib[kind_of(sharded)]:
+            sharded, alt = alt, sharded
     local.set_option("profile", 1)
     barrier()
     lat = np.empty(args.steps)
@@ -242,7 +285,9 @@ def main():
     qps = args.steps / elapsed
     kern_s = scan_ns * 1e-9 / max(scan_launches, 1)
     headline_kernel = ("hdb_mfma_fused_kernel (single launch: query prep + row sample + threshold + filter pass over all rows + top-k)"
-                       if local.stat("fused") else
+                       if local.stat("fused") == 1 else
+                       "hdb_mfma_kernel MODE 2 (single launch: query prep + row sample + thresholds + filter pass over all rows + top-k)"
+                       if local.stat("fused") == 2 else
                        "hdb_mfma_kernel (MFMA row scan, filter pass over all rows)" if local.stat("mfma")
                        else "hdb_scan_kernel (VALU row scan, filter pass over all rows)")
     alg_bytes = (hi - lo) * args.d * elem                    # per launch of the dominant kernel, per GPU
@@ -306,10 +351,44 @@ def main():
         except Exception:
             traffic = None
 
-    exchange_desc = ("none" if world == 1 else
-                     "shared-memory swap of the ranks' host records + host merge, once per query" if sharded._hx is not None
-                     else "1 RCCL all-gather of packed top-k per query + merge kernel")
+    exchange_desc = kind_of(sharded)
+    exchange_alt = None
+    if alt is not None:
+        barrier()
+        exchange_alt = {"kind": kind_of(alt), "p50_ms": 1e3 * p50_of(alt, min(args.steps, 50)),
+                        "calibration_p50_ms": {k: 1e3 * v for k, v in (calib or {}).items()}}
+        alt.close()
     sharded.close()
+
+    # ---------------- the drop-in API on the same matrix (one GPU) ----------------------------------
+    api = None
+    if rank == 0 and world == 1:
+        import hyperdb.ranking_algorithm as ranking
+        from hyperdb import HyperDB
+        steps_api = min(args.steps, 200)
+        qs = [Q[args.warmup + (i % args.steps)].cpu().numpy() for i in range(steps_api)]      # host float32 queries
+        for i in range(5):
+            ranking.hyperDB_ranking_algorithm_sort(local, qs[i], top_k=args.k, metric=args.metric)
+        t_sort = np.empty(steps_api)
+        for i in range(steps_api):
+            t0 = time.perf_counter()
+            ranking.hyperDB_ranking_algorithm_sort(local, qs[i], top_k=args.k, metric=args.metric)
+            t_sort[i] = time.perf_counter() - t0
+        db = HyperDB(fp_precision="float16" if args.dtype == "fp16" else "float32")
+        db._index = local                                 # the resident matrix of this run: documents are their own row numbers
+        db.documents = range(hi - lo)
+        db.source_indices = range(hi - lo)
+        for i in range(5):
+            db.query(qs[i] + 1e-3, top_k=args.k, metric=args.metric)
+        t_query = np.empty(steps_api)
+        for i in range(steps_api):
+            t0 = time.perf_counter()
+            db.query(qs[i], top_k=args.k, metric=args.metric)
+            t_query[i] = time.perf_counter() - t0
+        db._index = None
+        api = {"sort_p50_ms": 1e3 * float(np.median(t_sort)), "query_p50_ms": 1e3 * float(np.median(t_query)),
+               "kernel_path_p50_ms": 1e3 * float(np.median(lat)), "queries": "numpy float32 on the host",
+               "entry_points": "hyperdb.ranking_algorithm.hyperDB_ranking_algorithm_sort(handle, q, top_k) / HyperDB.query(q, top_k)"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -339,7 +418,10 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": scan_launches},
             "cpu_baseline": cpu,
             "batched": batched,
+            "api": api,
         }
+        if exchange_alt is not None:
+            out["exchange_alt"] = exchange_alt
         if extras:
             out["extra"] = extras
         print(json.dumps(out))

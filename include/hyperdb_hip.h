@@ -113,6 +113,13 @@ int hdb_index_set_bias(hdb_index* ix, const float* dev_bias);
 int hdb_recency_bias(const double* dev_ts, int64_t n, double recency_bias, double ts_max, float* dev_out,
                      int device, void* stream);
 
+/* Both decays a HyperDB.query() call applies (hyperdb.py:1344 over the FILTERED documents, then ranking_algorithm.py:183 on
+ * those values): dev_out[i] = rb * exp(first_i - max first), first_i = rb * exp(-ts_max + dev_ts[i]), for the rows dev_mask keeps
+ * (NULL: all rows; dropped rows get 0).  ts_max / ts_min = newest / oldest timestamp among the kept rows (the maximum of
+ * `first` sits at one of them).  float64 arithmetic, float32 result: the whole recency term of the facade without a host pass. */
+int hdb_recency_bias_twice(const double* dev_ts, const uint8_t* dev_mask, int64_t n, double recency_bias, double ts_max,
+                           double ts_min, float* dev_out, int device, void* stream);
+
 /* Optional row subset (filters / skip_doc, hyperdb.py:1119-1134,:1258-1308): dev_mask is n bytes,
  * non-zero = row takes part; NULL clears.  Excluded rows score -inf and are never returned
  * while at least k rows are included. */

@@ -12,6 +12,7 @@
 #include "hdb_common.h"
 #include "../../include/hyperdb_hip.h"
 #include <string>
+#include <cmath>
 #include <cstring>
 #include <cstdio>
 #include <algorithm>
@@ -43,6 +44,7 @@ int hdb_launch_merge(const void* idx_base, int64_t idx_stride, const void* score
 int hdb_launch_rowstats(const void* V, int64_t n, int d, int dtype, float* pscale, void* stream);
 int hdb_launch_qcentre(const void* Q, int nq, int d, bool f64, void* Qc, float* qscale, void* stream);
 int hdb_launch_recency(const double* ts, int64_t n, double rb, double ts_max, float* out, void* stream);
+int hdb_launch_recency2(const double* ts, const uint8_t* mask, int64_t n, double rb, double ts_max, double first_max, float* out, void* stream);
 int hdb_launch_maskbias(const uint8_t* mask, const float* bias, int64_t n, float* out, void* stream);
 int hdb_mfma_supported(int dtype, int d, int metric);
 int hdb_mfma_tile_rows(int dtype, int d);
@@ -954,6 +956,17 @@ extern "C" int hdb_recency_bias(const double* dev_ts, int64_t n, double recency_
     if (n == 0) return HDB_OK;
     HIP_TRY(hipSetDevice(device));
     LAUNCH_TRY(hdb_launch_recency(dev_ts, n, recency_bias, ts_max, dev_out, stream));
+    return HDB_OK;
+}
+
+extern "C" int hdb_recency_bias_twice(const double* dev_ts, const uint8_t* dev_mask, int64_t n, double recency_bias, double ts_max,
+                                      double ts_min, float* dev_out, int device, void* stream) {
+    if (n < 0 || (n > 0 && (!dev_ts || !dev_out))) return fail(HDB_ERR_ARG, "hdb_recency_bias_twice: null argument");
+    if (n == 0) return HDB_OK;
+    HIP_TRY(hipSetDevice(device));
+    // max over the kept rows of first_i = rb * exp(-ts_max + ts_i): at the newest row for rb > 0 (exp(0) = 1), at the oldest for rb < 0
+    const double first_max = recency_bias >= 0.0 ? recency_bias * std::exp(-ts_max + ts_max) : recency_bias * std::exp(-ts_max + ts_min);
+    LAUNCH_TRY(hdb_launch_recency2(dev_ts, dev_mask, n, recency_bias, ts_max, first_max, dev_out, stream));
     return HDB_OK;
 }
 

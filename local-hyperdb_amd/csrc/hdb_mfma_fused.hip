@@ -17,7 +17,10 @@ extern "C" int hdb_mfma_fused_supported(int dtype, int d, int metric, int nq, ui
     // euclidean (the MFMA expansion + direct re-score of near-duplicates in the last workgroup): fp16 matrices only -- the
     // float32 VALU pipelines compute the direct difference, which this kernel's float32 flavour does not; d = 768 would spill
     // three registers (those calls take the batched single launch, hdb_mfma_kernel.h MODE 2)
-    return shape && (metric == HDB_DOT || metric == HDB_COSINE || (metric == HDB_EUCLIDEAN && dtype == HDB_F16 && d != 768)) && nq >= 1 && nq <= maxq && kk <= 128;
+    // (euclidean, 2-4 queries: wave 0 pays sqrt + rcp on all 16 MFMA columns -- 199 vs 182 us at N=1.25M d=384 with four queries; those
+    // calls take the batched single launch, where eight waves share the epilogue)
+    const bool euclid = metric == HDB_EUCLIDEAN && dtype == HDB_F16 && d != 768 && nq == 1;
+    return shape && (metric == HDB_DOT || metric == HDB_COSINE || euclid) && nq >= 1 && nq <= maxq && kk <= 128;
 }
 
 // bytes of the persistent control block: 64 words of counters + the granules

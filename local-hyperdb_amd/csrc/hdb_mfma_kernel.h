@@ -951,20 +951,26 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
                     const float* qv = static_cast<const float*>(f.Qraw) + (int64_t)q * D;
                     const float close2 = 0.05f * ssq;
                     const E* Vr = static_cast<const E*>(a.V);
-                    for (uint32_t e = (uint32_t)w; e < nc; e += 8u) {
-                        const unsigned long long ent = buf[e];
+                    // every lane tests an entry of its own (64 per wave and step: nearly always none qualifies); the rare
+                    // near-duplicate is then re-scored by the whole wave
+                    for (uint32_t e0 = (uint32_t)w * 64u; e0 < nc; e0 += 8u * 64u) {
+                        const uint32_t e = e0 + (uint32_t)lane;
+                        const unsigned long long ent = e < nc ? buf[e] : 0ull;
                         const uint32_t row = 0xFFFFFFFFu - (uint32_t)(ent & 0xFFFFFFFFull);
-                        float s = hdb_key2f((uint32_t)(ent >> 32));
-                        const float bb = HAS_BIAS ? a.bias[row] : 0.f;
-                        const float sim = s - bb;
+                        const float s0 = hdb_key2f((uint32_t)(ent >> 32));
+                        const float bb = (HAS_BIAS && e < nc) ? a.bias[row] : 0.f;
+                        const float sim = s0 - bb;                             // 1 / (1 + dist) in (0, 1]; -inf for an excluded row
                         const float dist = 1.f / sim - 1.f;
-                        if (sim > 0.f && dist * dist < close2) {           // wave-uniform: one entry per wave
+                        unsigned long long todo = __ballot(e < nc && sim > 0.f && dist * dist < close2);
+                        while (todo) {
+                            const int src = (int)__ffsll((long long)todo) - 1;
+                            todo &= todo - 1ull;
+                            const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)row, src);
                             float accd = 0.f;
-                            for (int kx = lane; kx < D; kx += 64) { const float df = (float)Vr[(int64_t)row * D + kx] - qv[kx]; accd += df * df; }
+                            for (int kx = lane; kx < D; kx += 64) { const float df = (float)Vr[(int64_t)r * D + kx] - qv[kx]; accd += df * df; }
 #pragma unroll
                             for (int o = 32; o > 0; o >>= 1) accd += __shfl_xor(accd, o, 64);
-                            s = hdb_canon(1.f / (1.f + sqrtf(accd)) + bb);
-                            if (lane == 0) buf[e] = hdb_pack(s, row);
+                            if (lane == src) buf[e] = hdb_pack(hdb_canon(1.f / (1.f + sqrtf(accd)) + bb), row);
                         }
                     }
                     __syncthreads();

@@ -528,6 +528,23 @@ extern "C" int hdb_launch_recency(const double* ts, int64_t n, double rb, double
     return (int)hipGetLastError();
 }
 
+// Both decays of a HyperDB.query() call in one pass (reference hyperdb.py:1344: first = rb * exp(-max(ts) + ts) over the
+// FILTERED documents, then ranking_algorithm.py:183: rb * exp(first - max(first))): the maxima are over the kept rows, which
+// the caller knows as two scalars (first is monotone in ts: its maximum sits at the newest kept row for rb > 0 and at the
+// oldest one for rb < 0).  float64 arithmetic, float32 result; rows the mask drops get 0 (they are never returned).
+__global__ __launch_bounds__(256) void hdb_recency2_kernel(const double* ts, const uint8_t* mask, int64_t n, double rb, double ts_max,
+                                                           double first_max, float* out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const bool keep = mask == nullptr || mask[i] != 0;
+        const double first = rb * exp(-ts_max + ts[i]);
+        out[i] = keep ? (float)(rb * exp(first - first_max)) : 0.f;
+    }
+}
+extern "C" int hdb_launch_recency2(const double* ts, const uint8_t* mask, int64_t n, double rb, double ts_max, double first_max, float* out, void* stream) {
+    hipLaunchKernelGGL(hdb_recency2_kernel, dim3(hdb_grid_for(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, ts, mask, n, rb, ts_max, first_max, out);
+    return (int)hipGetLastError();
+}
+
 // Pearson (ranking_algorithm.py:77-113): r = sum((v-mv)(q-mq)) / (sd_v * sd_q * d).  Because sum(q-mq) = 0 the
 // numerator is the plain dot product of v with the CENTRED query, so pearson runs on the cosine pipeline with
 // two substitutions: per-row scale 1/(sd_v*d) instead of 1/||v|| (NaN for a constant row, like the reference's

@@ -37,7 +37,7 @@ EXPORTS = (
     "hdb_index_gather", "hdb_index_set_row_base", "hdb_index_destroy",
     "hdb_group_create", "hdb_group_topk_host", "hdb_group_destroy",
     "hdb_index_has_nan", "hdb_index_set_bias", "hdb_index_set_row_mask", "hdb_scores", "hdb_topk",
-    "hdb_topk_exact", "hdb_merge_topk", "hdb_set_option", "hdb_get_stat", "hdb_recency_bias",
+    "hdb_topk_exact", "hdb_merge_topk", "hdb_set_option", "hdb_get_stat", "hdb_recency_bias", "hdb_recency_bias_twice",
     "hdb_packed_bytes", "hdb_merge_topk_packed", "hdb_merge_topk_host", "hdb_host_exchange_merge", "hdb_topk_host",
 )
 
@@ -78,6 +78,7 @@ def _load():
     lib.hdb_set_option.argtypes = [vp, cp, i64]
     lib.hdb_get_stat.argtypes = [vp, cp, ctypes.POINTER(i64)]
     lib.hdb_recency_bias.argtypes = [vp, i64, ctypes.c_double, ctypes.c_double, vp, ctypes.c_int, vp]
+    lib.hdb_recency_bias_twice.argtypes = [vp, vp, i64, ctypes.c_double, ctypes.c_double, ctypes.c_double, vp, ctypes.c_int, vp]
     lib.hdb_topk_host.argtypes = [vp, vp, i32, i32, ctypes.c_int, vp, vp]
     lib.hdb_packed_bytes.argtypes = [i32, i32]
     lib.hdb_merge_topk_packed.argtypes = [vp, i32, i32, i32, vp, vp, vp, ctypes.c_int, vp]
@@ -169,6 +170,7 @@ class GpuIndex:
         self._mask = None
         self._nan = None
         self._buf = None
+        self._qstage = OrderedDict()           # (nq, d, dtype) -> (pinned host tensor, its numpy view, device tensor or None)
         self._host_records = OrderedDict()     # (nq, k) -> pinned record + views, owned by THIS index (small LRU)
         with torch.cuda.device(self.device):
             _check(_lib.hdb_index_create(ctypes.byref(self._h), ctypes.c_void_p(t.data_ptr()), self.n, self.d,
@@ -182,6 +184,8 @@ class GpuIndex:
             self._h = ctypes.c_void_p()
         if getattr(self, "_host_records", None):
             self._host_records.clear()                 # releases the pinned host memory
+        if getattr(self, "_qstage", None):
+            self._qstage.clear()
         self._buf = None
 
     def __del__(self):
@@ -265,8 +269,9 @@ class GpuIndex:
     def set_bias(self, bias):
         """bias: None, or N floats (numpy / torch) added to every score before top-k."""
         if bias is None:
-            self._bias = None
-            _check(_lib.hdb_index_set_bias(self._h, None), "hdb_index_set_bias")
+            if self._bias is not None:                     # (nothing set: nothing to clear -- saves a C call per query)
+                self._bias = None
+                _check(_lib.hdb_index_set_bias(self._h, None), "hdb_index_set_bias")
             return
         if isinstance(bias, torch.Tensor):
             b = bias.to(self.device, torch.float32).contiguous()
@@ -308,12 +313,26 @@ class GpuIndex:
         self._bias = out
         _check(_lib.hdb_index_set_bias(self._h, ctypes.c_void_p(out.data_ptr())), "hdb_index_set_bias")
 
+    def recency_twice(self, ts_dev, mask_dev, recency_bias, ts_max, ts_min):
+        """Both decays of a HyperDB.query() call (reference hyperdb.py:1344, then ranking_algorithm.py:183) for the rows
+        `mask_dev` keeps, from a resident float64 timestamp column: -> float32 CUDA tensor (hdb_recency_bias_twice).
+        ts_max / ts_min: newest / oldest timestamp among the kept rows."""
+        out = torch.empty(self.n, dtype=torch.float32, device=self.device)
+        _check(_lib.hdb_recency_bias_twice(ctypes.c_void_p(ts_dev.data_ptr()),
+                                           ctypes.c_void_p(mask_dev.data_ptr()) if mask_dev is not None else None, self.n,
+                                           float(recency_bias), float(ts_max), float(ts_min), ctypes.c_void_p(out.data_ptr()),
+                                           self.device.index or 0, _stream_ptr(self.device)), "hdb_recency_bias_twice")
+        return out
+
     def set_row_mask(self, mask):
         if mask is None:
-            self._mask = None
-            _check(_lib.hdb_index_set_row_mask(self._h, None), "hdb_index_set_row_mask")
+            if self._mask is not None:
+                self._mask = None
+                _check(_lib.hdb_index_set_row_mask(self._h, None), "hdb_index_set_row_mask")
             return
-        if isinstance(mask, torch.Tensor):
+        if isinstance(mask, torch.Tensor) and mask.dtype == torch.uint8 and mask.device == self.device and mask.is_contiguous():
+            m = mask                                       # a resident 0/1 mask (HyperDB caches them per filter): borrowed as it is
+        elif isinstance(mask, torch.Tensor):
             m = (mask != 0).to(self.device, torch.uint8).contiguous()
         else:
             m = torch.from_numpy(np.ascontiguousarray((np.asarray(mask) != 0).astype(np.uint8))).to(self.device)
@@ -332,12 +351,42 @@ class GpuIndex:
         return int(v.value)
 
     # -- queries -------------------------------------------------------------------------------
-    def _query_tensor(self, q, batched):
+    def _stage_host_query(self, q):
+        """A host query batch for a SYNCHRONOUS call: converted once into a cached pinned buffer.  Up to 4 queries are read by
+        the kernels straight from that buffer (pinned host memory is device-visible: 1.5 KB per query over PCIe costs less
+        than a copy on the stream ahead of the launch); larger batches go through one asynchronous copy into a cached device
+        tensor.  (The reference hands numpy queries to numpy: hyperdb.py:1556.)"""
+        npdt = np.float64 if self.dtype == HDB_F64 else np.float32
+        a = np.asarray(q)
+        if a.ndim == 1:
+            a = a.reshape(1, -1)
+        if a.ndim != 2 or a.shape[1] != self.d:
+            raise ValueError(f"shapes ({self.n},{self.d}) and {tuple(np.asarray(q).shape)} not aligned")
+        nq = int(a.shape[0])
+        key = (nq, npdt)
+        slot = self._qstage.get(key)
+        if slot is None:
+            pin = torch.empty((nq, self.d), dtype=torch.float64 if npdt is np.float64 else torch.float32, pin_memory=True)
+            dev = None if nq <= 4 else torch.empty((nq, self.d), dtype=pin.dtype, device=self.device)
+            slot = self._qstage[key] = (pin, pin.numpy(), dev)
+            while len(self._qstage) > HOST_RECORD_SLOTS:
+                self._qstage.popitem(last=False)
+        else:
+            self._qstage.move_to_end(key)
+        np.copyto(slot[1], a, casting="unsafe")
+        if slot[2] is None:
+            return slot[0]
+        slot[2].copy_(slot[0], non_blocking=True)
+        return slot[2]
+
+    def _query_tensor(self, q, batched, staged=False):
         qdt = torch.float64 if self.dtype == HDB_F64 else torch.float32
+        if staged and batched and not isinstance(q, torch.Tensor):
+            return self._stage_host_query(q)
         if isinstance(q, torch.Tensor):
-            if batched and q.dtype == qdt and q.dim() == 2 and q.shape[1] == self.d and q.device == self.device \
-                    and q.is_contiguous():
-                return q                                 # the per-query fast path: nothing to convert
+            if batched and q.dtype == qdt and q.dim() == 2 and q.shape[1] == self.d and q.is_contiguous() and \
+                    (q.device == self.device or (staged and q.device.type == "cpu" and q.is_pinned())):
+                return q                                 # the per-query fast path: nothing to convert (or: already staged)
             t = q.to(self.device, qdt)
         else:
             t = torch.from_numpy(np.ascontiguousarray(np.asarray(q, dtype=np.float64))).to(self.device, qdt)
@@ -390,7 +439,7 @@ class GpuIndex:
         rare exact re-run.  Returns numpy VIEWS (idx int64 [nq,k], score float32 [nq,k], status int32 [nq]) that are
         overwritten by the next call of THIS index with the same (nq, k); the record belongs to the index (two
         indices, devices or shard groups never share one) and at most HOST_RECORD_SLOTS shapes are kept."""
-        qt = self._query_tensor(Q, batched=True)
+        qt = self._query_tensor(Q, batched=True, staged=True)
         nq, k = int(qt.shape[0]), int(k)
         slot = self._host_records.get((nq, k))
         if slot is None:                                 # pinned record + its numpy views, built once per (nq, k)
@@ -409,7 +458,7 @@ class GpuIndex:
 
     def topk_record_host(self, Q, k, metric_id):
         """topk_views, but returns the whole packed record as ONE uint8 numpy view (what a shard hands to the exchange)."""
-        qt = self._query_tensor(Q, batched=True)
+        qt = self._query_tensor(Q, batched=True, staged=True)
         nq = int(qt.shape[0])
         self.topk_views(qt, k, metric_id)
         return self._host_records[(nq, int(k))][5]

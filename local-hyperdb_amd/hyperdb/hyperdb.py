@@ -5,8 +5,8 @@ takes documents + precomputed vectors, ``query()`` with the reference's signatur
 and the ~30 lines of ``_execute_query`` around the ranking call (hyperdb.py:1461-1469, :1541-1575).
 Also here, from the "next" rows of SURVEY.md section 8f: ``load`` (and its inverse ``save``) in the reference's own
 pickle, json and sqlite layouts (hyperdb.py:769-1005) so an existing database file goes straight into HBM.  Everything
-else the reference class does (sentence-transformer embedding, Annoy, the text filters ``key`` and ``sentence``) is out
-of scope and is NOT re-implemented here; a caller that has its own text predicate passes its result as a ``mask`` filter.
+else the reference class does (sentence-transformer embedding, Annoy, the ``key`` filter that re-embeds sub-documents) is
+out of scope and is NOT re-implemented here; a caller that has its own predicate passes its result as a ``mask`` filter.
 
 Matrix residency: the N x d matrix lives ONLY in HBM (there is no host mirror; ``.vectors`` copies it back on demand).
 ``remove_document`` tombstones the rows (O(1) on the device: they join every query's row mask) and compacts the matrix
@@ -20,9 +20,12 @@ Differences from the reference, all deliberate:
     O(N) Python index rebuild on every add/remove (hyperdb.py:218-220);
   * ranked rows map to documents by row id, O(k), instead of ``self.documents.index(document)``
     (hyperdb.py:1568, O(N) dict comparisons per hit);
-  * ``filters``: ``skip_doc`` and ``metadata`` equality become a device row mask, and so does the additive
-    ``("mask", bool_array)`` filter; ``key`` (re-embeds sub-documents, hyperdb.py:1087) and ``sentence`` (text search,
-    hyperdb.py:1136-1176) belong to the text pipeline and raise NotImplementedError;
+  * ``filters``: ``skip_doc``, ``metadata`` equality and ``sentence`` (whole-word text search, hyperdb.py:1136-1176: a host
+    predicate over token sets built once per document list) become a device row mask, cached on the device per filter, and so
+    does the additive ``("mask", bool_array)`` filter; ``key`` (re-embeds sub-documents, hyperdb.py:1087) needs the embedding
+    pipeline and raises NotImplementedError;
+  * recency: the timestamps of a key are a resident float64 column; both decays of a query are one kernel
+    (hdb_recency_bias_twice) whose result is kept per (key, filter, recency_bias) -- no O(N) host array per query;
   * strings can be queried only when an ``embedding_function`` is supplied (no model download);
   * additive ``devices=[...]``: the matrix is row-sharded over several GPUs and every query runs on all of them in one
     call of the same single-process API (``GpuGroup`` -> hdb_group_topk_host).
@@ -37,11 +40,14 @@ import datetime
 import gzip
 import json
 import pickle
+import re
 import sqlite3
+import string
 from collections import OrderedDict
 from contextlib import closing
 
 import numpy as np
+import torch
 
 from . import ranking_algorithm as ranking
 from ._native import GpuIndex, METRIC_IDS
@@ -76,6 +82,12 @@ class HyperDB:
         self._index = None
         self._dead = np.zeros(0, dtype=np.int64)     # tombstoned device rows (ascending); see remove_document
         self._ts_cache = {}                           # timestamp_key -> float64 array over documents (NaN = missing)
+        # resident per-row inputs of the ranking call, rebuilt only when the document list changes (_invalidate_rows):
+        self._mask_cache = OrderedDict()              # filter key -> (per-shard uint8 device masks | None, documents kept, bool array over documents | None)
+        self._ts_dev = {}                             # timestamp_key -> per-shard float64 device columns over the device rows
+        self._bias_cache = OrderedDict()              # (timestamp_key, filter key, recency_bias) -> per-shard float32 device bias
+        self._str_tokens = None                       # per document: token sets of the strings inside it (sentence filter)
+        self.host_row_passes = 0                      # O(N) host arrays built so far (cache misses only; tests watch it)
         self._cache = OrderedDict()
         self._cache_size = cache_size
         self.cache_hits = self.cache_misses = 0
@@ -117,8 +129,7 @@ class HyperDB:
         start = len(self.documents)
         self.documents = list(self.documents) + list(documents)
         self.source_indices = list(self.source_indices) + list(range(start, start + len(documents)))
-        self._ts_cache.clear()
-        self.clear_cache()
+        self._invalidate_rows()
         if self._index is None:
             self._index = GpuGroup(vectors, self.devices) if self.devices else GpuIndex(vectors, device=self.device)
         else:
@@ -161,6 +172,22 @@ class HyperDB:
             out.append(doc)
         return out
 
+    def _invalidate_rows(self):
+        """The document list or the device rows changed: every per-row cache is stale."""
+        self._ts_cache.clear()
+        self._mask_cache.clear()
+        self._ts_dev.clear()
+        self._bias_cache.clear()
+        self._str_tokens = None
+        self.clear_cache()
+
+    def _shards(self):
+        """[(GpuIndex, first device row, end device row)] -- one entry, or one per GPU of a GpuGroup."""
+        ix = self._index
+        if isinstance(ix, GpuGroup):
+            return [(sh, lo, hi) for sh, (lo, hi) in zip(ix.shards, ix.bounds)]
+        return [(ix, 0, ix.n)]
+
     # device row of every live document (identity while nothing is tombstoned)
     def _live_rows(self):
         if self._index is None:
@@ -197,14 +224,15 @@ class HyperDB:
         kept_src = [s_ for s_ in self.source_indices if s_ not in gone]     # :737-745
         drop_arr = np.asarray(drop)
         self.source_indices = [int(s_ - np.searchsorted(drop_arr, s_)) for s_ in kept_src]
-        self._ts_cache.clear()
-        self.clear_cache()
+        self._invalidate_rows()
         if self._index is None:
             return
         if not self.documents:
             self._index.close()
             self._index, self._dead = None, np.zeros(0, dtype=np.int64)
-        elif self._dead.size * 4 > self._index.n:
+        elif self._dead.size * 4 > self._index.n or self._index.has_nan:
+            # (a stored NaN: the library's flag covers tombstoned rows too, and the reference answers normally as soon as the
+            # NaN document is gone -- compact at once, the gather recomputes the flag over the rows it keeps)
             self._index.compact(self._live_rows())
             self._dead = np.zeros(0, dtype=np.int64)
 
@@ -239,6 +267,10 @@ class HyperDB:
             query_input = tuple(query_input.ravel().tolist()) + (query_input.shape,)
         elif isinstance(query_input, list):
             query_input = tuple(np.asarray(query_input).ravel().tolist())
+        return (query_input, top_k, return_similarities, HyperDB._filter_key(filters), recency_bias, timestamp_key, metric, ann_percent)
+
+    @staticmethod
+    def _filter_key(filters):
         def freeze(p):
             if isinstance(p, dict):
                 return tuple(sorted(p.items()))
@@ -247,8 +279,7 @@ class HyperDB:
             if isinstance(p, (list, tuple)):
                 return tuple(p)
             return p
-        hf = None if filters is None else tuple((name, freeze(p)) for name, p in filters)
-        return (query_input, top_k, return_similarities, hf, recency_bias, timestamp_key, metric, ann_percent)
+        return None if not filters else tuple((name, freeze(p)) for name, p in filters)
 
     # ---------------------------------------------------------------- helpers around the ranking call
     @staticmethod
@@ -336,14 +367,43 @@ class HyperDB:
                     raise ValueError(f"mask filter needs one boolean per document ({n}), got {m.size}")
                 keep &= m
             elif name == 'sentence':
-                raise NotImplementedError("filter 'sentence' is a text search (hyperdb.py:1136-1176): out of scope here; "
-                                          "evaluate the predicate on the host and pass ('mask', bool_array) instead")
+                # whole-word text search (hyperdb.py:1136-1176): a document passes a filter when ONE string inside it holds
+                # every word of the filter; several filters must all pass.  The strings of every document are tokenised once
+                # (until the document list changes) instead of once per query.
+                wanted = [self.tokenize(w) for w in (params if isinstance(params, (list, tuple)) else [params])]
+                if self._str_tokens is None:
+                    self._str_tokens = [self._string_token_sets(doc) for doc in self.documents]
+                keep &= np.fromiter((all(any(w <= toks for toks in sets) for w in wanted) for sets in self._str_tokens),
+                                    dtype=bool, count=n)
             elif name == 'key':
                 raise NotImplementedError("filter 'key' re-embeds sub-documents (hyperdb.py:1087): needs the embedding "
                                           "pipeline, which is out of scope here")
             else:
                 raise ValueError(f"Invalid filter name {name}")                # hyperdb.py:1279-1280
         return keep
+
+    _PUNCT = str.maketrans('', '', string.punctuation)
+    _WORD = re.compile(r'\w+')
+
+    @classmethod
+    def tokenize(cls, text):
+        """The set of lower-cased words of a string, punctuation dropped first (what hyperdb.py:1136-1141 compares)."""
+        return set(cls._WORD.findall(text.translate(cls._PUNCT).lower()))
+
+    @classmethod
+    def _string_token_sets(cls, doc):
+        """Token sets of every string reachable inside a document through dicts and lists (explicit stack, no recursion
+        limit); other leaves never match (hyperdb.py:1143-1158)."""
+        out, todo = [], [doc]
+        while todo:
+            obj = todo.pop()
+            if isinstance(obj, str):
+                out.append(cls.tokenize(obj))
+            elif isinstance(obj, dict):
+                todo.extend(obj.values())
+            elif isinstance(obj, list):
+                todo.extend(obj)
+        return out
 
     # ---------------------------------------------------------------- persistence (hyperdb.py:769-1005)
     def _data_dict(self):
@@ -424,8 +484,7 @@ class HyperDB:
             self._index.close()
         self._index, self._dead = None, np.zeros(0, dtype=np.int64)
         self.documents, self.source_indices = [], []
-        self._ts_cache.clear()
-        self.clear_cache()
+        self._invalidate_rows()
         documents = list(data["documents"])
         if len(documents):
             self.add(documents, vectors)
@@ -437,6 +496,67 @@ class HyperDB:
         self.vectors_normalized = data.get("vectors_normalized", False)
 
     # ---------------------------------------------------------------- query (hyperdb.py:1429-1586)
+    # Resident inputs of the ranking call.  Filters and tombstones become ONE row mask per shard, kept on the device per filter
+    # key; the timestamps of a key live on the device as a float64 column over the device rows; both decays of a query
+    # (hyperdb.py:1344 over the FILTERED documents, then ranking_algorithm.py:183) are one kernel over that column and the
+    # mask, and its result is kept per (key, filter, recency_bias).  A query whose inputs are cached builds no O(N) host array
+    # and uploads nothing; everything is dropped when the document list changes (_invalidate_rows).
+    _ROW_CACHE_SLOTS = 4
+
+    def _mask_for(self, filters):
+        """-> (per-shard device masks or None, number of documents kept, bool array over documents or None)."""
+        fkey = self._filter_key(filters)
+        hit = self._mask_cache.get(fkey)
+        if hit is not None:
+            self._mask_cache.move_to_end(fkey)
+            return hit
+        keep = self._row_mask(filters)                          # over documents (host predicates, once per filter key)
+        if keep is None and self._dead.size == 0:
+            hit = (None, len(self.documents), None)
+        else:
+            self.host_row_passes += 1
+            live = self._live_rows()
+            rows_kept = live if keep is None else live[keep]
+            row_mask = np.zeros(self._index.n, dtype=np.uint8)
+            row_mask[rows_kept] = 1
+            parts = [torch.from_numpy(row_mask[lo:hi]).to(sh.device) for sh, lo, hi in self._shards()]
+            hit = (parts, int(rows_kept.size), keep)
+        self._mask_cache[fkey] = hit
+        while len(self._mask_cache) > self._ROW_CACHE_SLOTS:
+            self._mask_cache.popitem(last=False)
+        return hit
+
+    def _bias_for(self, recency_bias, timestamp_key, filters, masks, keep):
+        """Per-shard device bias of both decays, or None when recency_bias == 0 (hyperdb.py:1320-1322)."""
+        if recency_bias == 0:
+            return None
+        if timestamp_key is None:
+            timestamp_key = "timestamp"
+        if timestamp_key not in self.metadata_keys:
+            raise ValueError(f"The timestamp_key '{timestamp_key}' must be present in metadata_keys when recency_bias is not 0.")
+        bkey = (timestamp_key, self._filter_key(filters), float(recency_bias))
+        hit = self._bias_cache.get(bkey)
+        if hit is not None:
+            self._bias_cache.move_to_end(bkey)
+            return hit
+        self.host_row_passes += 1
+        ts = self._timestamps(timestamp_key)                    # over documents (host, extracted once per key)
+        kept = ts if keep is None else ts[keep]
+        if np.isnan(kept).any():
+            raise ValueError("All timestamps must be populated when recency_bias is not 0 or timestamp_key is provided.")
+        cols = self._ts_dev.get(timestamp_key)
+        if cols is None:                                        # documents -> device rows (tombstoned rows keep a 0)
+            rows = np.zeros(self._index.n, dtype=np.float64)
+            rows[self._live_rows()] = np.nan_to_num(ts)
+            cols = self._ts_dev[timestamp_key] = [torch.from_numpy(rows[lo:hi]).to(sh.device) for sh, lo, hi in self._shards()]
+        t_max, t_min = float(np.max(kept)), float(np.min(kept))
+        hit = [sh.recency_twice(cols[p], None if masks is None else masks[p], recency_bias, t_max, t_min) if sh.n else None
+               for p, (sh, lo, hi) in enumerate(self._shards())]
+        self._bias_cache[bkey] = hit
+        while len(self._bias_cache) > self._ROW_CACHE_SLOTS:
+            self._bias_cache.popitem(last=False)
+        return hit
+
     def _execute(self, Q, top_k, return_similarities, filters, recency_bias, timestamp_key, metric):
         if self._index is None or not self.documents:
             raise Exception("The database is empty. Cannot proceed with the query.")
@@ -446,40 +566,25 @@ class HyperDB:
         ix = self._index
         if ix.has_nan or np.isnan(Q).any():
             raise ValueError(ranking.NAN_MESSAGE)
-        keep = self._row_mask(filters)                          # over documents
-        n_avail = len(self.documents) if keep is None else int(keep.sum())
+        masks, n_avail, keep = self._mask_for(filters)
         if n_avail == 0:
             print("INFO: No document matches your query with the brute-force method and the current filters.")
             return [[] for _ in range(len(Q))]
         if top_k > n_avail:
             print(f"Warning: top_k ({top_k}) is greater than the number of filtered documents ({n_avail}). Setting top_k to {n_avail}.")
             top_k = n_avail
-        # decay #1 (host, float64) over the documents the filters kept, like hyperdb.py:1555
-        first = self._handle_timestamps(recency_bias, timestamp_key, keep)
-        # documents -> device rows: filters and tombstones become ONE row mask
-        row_mask = None
-        rows_kept = None
-        if keep is not None or self._dead.size:
-            live = self._live_rows()
-            rows_kept = live if keep is None else live[keep]
-            row_mask = np.zeros(ix.n, dtype=bool)
-            row_mask[rows_kept] = True
+        bias = self._bias_for(recency_bias, timestamp_key, filters, masks, keep)
+        shards = self._shards()
         try:
-            ix.set_row_mask(row_mask)
-            if first is not None:
-                # decay #2, ranking_algorithm.py:183: rb * exp(first - max(first)) with the maximum over the kept rows
-                # only (the reference ranks the filtered rows); masked rows get the neutral exp(0) and are never returned
-                fmax = float(np.max(first))
-                if rows_kept is None:
-                    first_rows = first
-                else:
-                    first_rows = np.full(ix.n, fmax, dtype=np.float64)
-                    first_rows[rows_kept] = first
-                ix.set_recency(first_rows, recency_bias, ts_max=fmax)
+            for p, (sh, lo, hi) in enumerate(shards):
+                if sh.n:
+                    sh.set_row_mask(None if masks is None else masks[p])
+                    sh.set_bias(None if bias is None else bias[p])
             idx, sc = ix.topk(Q, int(top_k), METRIC_IDS[metric])
         finally:
-            ix.set_row_mask(None)
-            ix.set_bias(None)
+            for sh, lo, hi in shards:
+                sh.set_row_mask(None)
+                sh.set_bias(None)
         if n_avail == 1:
             print("Info: Only one document left.")                               # ranking_algorithm.py:189-191
         out = []

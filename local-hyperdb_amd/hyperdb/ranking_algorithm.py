@@ -224,8 +224,11 @@ def hyperDB_ranking_algorithm_sort(vectors, query_vector, top_k=5, metric='cosin
     """
     ix, _, owned = _resolve(vectors)
     try:
-        qh = _query_host(query_vector)
-        if ix.has_nan or np.isnan(qh).any():
+        # a CUDA tensor query stays on the device (its NaN check is the kernels' status word, which ix.topk turns into the
+        # same ValueError); a host query is checked here and staged once in a pinned buffer by the index
+        on_device = isinstance(query_vector, torch.Tensor) and query_vector.is_cuda and ix.n > 1
+        qh = query_vector.detach() if on_device else _query_host(query_vector)
+        if ix.has_nan or (not on_device and np.isnan(qh).any()):
             raise ValueError(NAN_MESSAGE)
         _validate_metric(metric)
         if ix.n == 0:

@@ -80,13 +80,34 @@ def test_host_helpers_without_gpu():
         db._row_mask([("skip_doc", 6)])
     with pytest.raises(NotImplementedError):
         db._row_mask([("key", "name")])
-    with pytest.raises(NotImplementedError):
-        db._row_mask([("sentence", "electric mouse")])          # text search: out of scope, callers pass a mask
     assert db._row_mask([("mask", [1, 0, 1, 1, 0, 0]), ("skip_doc", 1)]).tolist() == [False, False, True, True, False, False]
     with pytest.raises(ValueError):
         db._row_mask([("mask", [True, False])])
     with pytest.raises(ValueError):
         db._row_mask([("colour", "x")])
+
+
+def test_sentence_filter_semantics():
+    """Whole-word, punctuation-blind, case-blind, all words of a filter in ONE string of the document, all filters must hit
+    (reference hyperdb.py:1136-1176); strings are tokenised once per document list."""
+    from hyperdb import HyperDB
+    db = HyperDB()
+    db.documents = [{"name": "Pikachu", "info": {"description": "An electric mouse; it stores electricity!"}},
+                    {"name": "Raichu", "info": {"description": "Its tail discharges ELECTRICITY into the ground.", "tags": ["mouse", "electric"]}},
+                    "a plain string document about electricity",
+                    {"name": "Bulbasaur", "info": {"description": "A strange seed was planted on its back."}},
+                    42]
+    assert db._row_mask([("sentence", "electricity")]).tolist() == [True, True, True, False, False]
+    assert db._row_mask([("sentence", "Electric mouse")]).tolist() == [True, False, False, False, False]   # both words in one string
+    assert db._row_mask([("sentence", ["electricity", "tail"])]).tolist() == [False, True, False, False, False]
+    assert db._row_mask([("sentence", "electric")]).tolist() == [True, True, False, False, False]          # whole words only
+    assert db._row_mask([("sentence", "seed, planted!")]).tolist() == [False, False, False, True, False]
+    assert db._row_mask([("sentence", "seed"), ("skip_doc", -1)]).tolist() == [False, False, False, True, False]
+    assert HyperDB.tokenize("Hello, World! hello_world") == {"hello", "world", "helloworld"}
+    deep = {"a": [{"b": [{"c": "needle in a haystack"}]}]}
+    db.documents = [deep, {"x": 1}]
+    db._invalidate_rows()
+    assert db._row_mask([("sentence", "haystack needle")]).tolist() == [True, False]
 
 
 def test_dict_and_aliases_without_gpu():
@@ -325,6 +346,54 @@ def test_config1_pokemon_shaped_documents(capsys):
 
 
 @pytest.mark.gpu
+def test_recency_and_filters_stay_on_the_device():
+    """The timestamps of a key, the row mask of a filter and the bias of both decays are resident: after the first query of
+    a (filter, key, recency_bias) combination no O(N) host array is built (host_row_passes stands still), the answers equal
+    the host restatement of the reference tail, and any change of the document list drops the caches."""
+    from hyperdb import HyperDB
+    from oracle import ranking_oracle as orc
+    rng = np.random.default_rng(11)
+    n, d = 20_000, 128
+    V = rng.standard_normal((n, d)).astype(np.float32).astype(np.float16)
+    docs = [{"name": f"doc{i}", "info": {"type": "even" if i % 2 == 0 else "odd"}, "timestamp": 1.7e9 + 7.0 * i} for i in range(n)]
+    db = HyperDB(documents=docs, vectors=V, fp_precision="float16", metadata_keys=["timestamp", "info.type"], cache_size=4)
+    ts = np.array([x["timestamp"] for x in docs])
+    combos = [dict(recency_bias=0.5, timestamp_key="timestamp"),
+              dict(recency_bias=0.5, timestamp_key="timestamp", filters=[("skip_doc", -5000), ("metadata", {"info.type": "odd"})]),
+              dict(recency_bias=-0.3, timestamp_key="timestamp", filters=[("skip_doc", 1000)]),
+              dict(filters=[("metadata", {"info.type": "even"})])]
+    keeps = [np.ones(n, bool), np.array([i < 15_000 and i % 2 == 1 for i in range(n)]), np.arange(n) >= 1000, np.arange(n) % 2 == 0]
+    for kw in combos:
+        db.query(rng.standard_normal(d).astype(np.float16), top_k=10, **kw)          # fills the caches
+    passes = db.host_row_passes
+    assert passes > 0
+    for rnd in range(3):
+        for kw, keep in zip(combos, keeps):
+            q = rng.standard_normal(d).astype(np.float16)
+            res = db.query(q, top_k=10, **kw)
+            rb = kw.get("recency_bias", 0)
+            first = rb * np.exp(ts[keep] - ts[keep].max()) if rb else None
+            oi, osc = orc.rank(V[keep], q.copy(), top_k=10, metric="cosine_similarity", timestamps=first, recency_bias=rb)
+            got_i, got_s = [r[2] for r in res], np.array([r[1] for r in res])
+            assert orc.same_result_modulo_ties(np.array(got_i), got_s, np.nonzero(keep)[0][oi], osc, 1e-3), kw
+    assert db.host_row_passes == passes, "cached combinations must not build O(N) host arrays"
+    db.remove_document([3, 4, 5])                                 # tombstones: every per-row cache is rebuilt once
+    res = db.query(V[10], top_k=3, recency_bias=0.5, timestamp_key="timestamp")
+    assert db.host_row_passes > passes and res[0][0]["name"] == "doc10"
+    p2 = db.host_row_passes
+    db.query(V[11], top_k=3, recency_bias=0.5, timestamp_key="timestamp")
+    assert db.host_row_passes == p2
+    # a stored NaN document: queries raise like the reference (:150-151) until it is removed, then answer at once (ADVICE r2)
+    W = rng.standard_normal((200, 32)).astype(np.float32)
+    W[17, 3] = np.nan
+    db2 = HyperDB(documents=[f"d{i}" for i in range(200)], vectors=W)
+    with pytest.raises(ValueError, match="NaN"):
+        db2.query(W[0], top_k=3)
+    db2.remove_document(17)
+    assert db2.query(W[0], top_k=1, metric="dot_product")[0][0] == "d0"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fmt,name", [("pickle", "db.pickle.gz"), ("pickle", "db.pickle"), ("json", "db.json"), ("sqlite", "db.sqlite")])
 def test_save_load_round_trip_and_mask_filter(tmp_path, fmt, name):
     """A database written in the reference's layout comes back into HBM and answers like the original; a caller-
@@ -351,6 +420,8 @@ def test_save_load_round_trip_and_mask_filter(tmp_path, fmt, name):
     hits = db2.query(q, top_k=50, filters=[("mask", mouse)])
     assert len(hits) == 30 and all(r[0]["text"].startswith("electric mouse") for r in hits)
     assert hits[0][0]["name"] == "doc40"
+    words = db2.query(q, top_k=50, filters=[("sentence", "electric mouse")])        # the reference's text filter: same rows
+    assert [r[2] for r in words] == [r[2] for r in hits] and np.allclose([r[1] for r in words], [r[1] for r in hits])
     half = HyperDB(fp_precision="float16")
     half.load(path, format=fmt)                                    # lands in HBM in the requested precision
     assert half.vectors.dtype == np.float16 and half.query(q.astype(np.float16), top_k=1)[0][0]["name"] == "doc40"

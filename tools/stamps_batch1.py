@@ -28,7 +28,7 @@ def run():
     lib = _native.lib()
     lib.hdb_debug_read_batch_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
     names = ['start(max)', 'prepared', 'sample done', 'published', 'owner done', 'thr known', 'pass done', 'arrived', 'all arrived', 'sorted', 'left']
-    for (n, nq, metric) in ((1_250_000, 8, 'cosine_similarity'), (1_250_000, 1, 'euclidean_metric'), (10_000_000, 256, 'dot_product'), (10_000_000, 16, 'cosine_similarity')):
+    for (n, nq, metric) in ((1_250_000, 8, 'cosine_similarity'), (1_250_000, 5, 'euclidean_metric'), (10_000_000, 256, 'dot_product'), (10_000_000, 16, 'cosine_similarity')):
         V, lo, hi = bench.make_shard(n, 384, torch.float16, 0, 1, dev)
         ix = GpuIndex(V)
         Q = bench.make_queries(nq, 384, torch.float16, dev).to(torch.float32)
