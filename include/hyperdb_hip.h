@@ -193,14 +193,15 @@ int hdb_host_exchange_merge(void* shm, int64_t stride, int32_t world, int32_t ra
 
 /* Single-process multi-GPU group: HyperDB.query() (hyperdb.py:1584) is a single-process
  * call, so the row-sharded matrix must be reachable without a launcher.  A group is `parts` row shards, each an hdb_index
- * created on its own device with its row_base (a device may hold several shards).  hdb_group_topk_host uploads the
- * queries (HOST memory, nq x d float32, or float64 for F64 matrices) to every shard's device, runs hdb_topk on every
- * shard concurrently (one parked worker thread and one stream per shard), lets each shard's last kernel store its packed
- * record into a pinned, portable host buffer that every device can write, waits for every shard's stream, merges the
- * `parts` records on the host (as hdb_merge_topk_host) and returns the merged packed record (hdb_packed_bytes layout) in
- * host_record.  Queries whose sampled threshold failed on any shard are re-run through hdb_topk_exact on every shard
- * before returning: on return every status word is 0 except HDB_Q_NAN.  Bias / mask are set per shard on the shards'
- * own handles (recency: pass the GLOBAL newest timestamp as ts_max to hdb_recency_bias).  parts * k <= 8192.
+ * created on its own device with its row_base (a device may hold several shards).  hdb_group_topk_host copies the
+ * queries (HOST memory, nq x d float32, or float64 for F64 matrices) into a pinned staging buffer every device can read,
+ * runs hdb_topk_host on every shard concurrently (one worker thread and one stream per shard; between calls a worker spins
+ * briefly on the job word, then parks), lets each shard's last kernel store its packed record into a pinned, portable
+ * host buffer that every device can write, merges the `parts` records on the host (as hdb_merge_topk_host) and returns
+ * the merged packed record (hdb_packed_bytes layout) in host_record.  A shard whose sampled threshold failed re-runs those
+ * queries locally through the exact selection before it reports: on return every status word is 0 except HDB_Q_NAN.
+ * Bias / mask are set per shard on the shards' own handles (recency: pass the GLOBAL newest timestamp as ts_max to
+ * hdb_recency_bias).  Any k the single index takes is accepted (the merge runs on the host).
  * The group borrows the shard handles: destroy the group first, then the shards. */
 typedef struct hdb_group hdb_group;
 int hdb_group_create(hdb_group** out, hdb_index* const* shards, int32_t parts);

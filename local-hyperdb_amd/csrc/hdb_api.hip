@@ -974,15 +974,20 @@ extern "C" int hdb_recency_bias_twice(const double* dev_ts, const uint8_t* dev_m
 // Single-process multi-GPU group: one row shard per entry (its own hdb_index, device and stream), queried together
 // behind ONE call -- what HyperDB.query() (hyperdb/hyperdb.py:1584, a single-process call) needs to reach several
 // GPUs without torchrun.  Per call:
-//   worker thread p (one per shard, parked on a condition variable between calls; launching 8 shards' pipelines from one
-//   host thread would serialise ~8 x 20 us of launch work, more than a shard's 150 us scan):
-//       H2D copy of the queries -> hdb_topk on the shard's own stream, results stored by the last kernel STRAIGHT into
-//       slice p of a pinned, portable host buffer (every device can write it: the "peer-readable record buffer") -> event
-//   calling thread: merge stream (device of shard 0) waits for the P events, hdb_merge_kernel reads the P records and
-//       stores the merged record into pinned host memory, one hipStreamSynchronize.
+//   calling thread: copies the queries into a pinned, portable staging buffer (every device can read it), publishes the job
+//       (an atomic sequence number) and waits for the shards' arrival counter -- spinning first, a condition variable only
+//       when a call takes longer than the spin window;
+//   worker thread p (one per shard; between calls it spins on the sequence number for a short window, then parks on the
+//       condition variable: a query stream never pays a futex wake-up): hdb_topk_host on the shard's own stream -- up to four
+//       queries are read by the kernels straight from the staging buffer, larger batches go through one asynchronous copy --
+//       which lets the shard's last kernel store its packed record STRAIGHT into slice p of a pinned, portable host buffer,
+//       status words last, polls those words instead of waiting for the stream, and re-runs a failed threshold locally
+//       through the exact selection (per-shard exactness is all the merge needs);
+//   calling thread: k-way merge of the P records on the host (merge_host_records): no merge launch, no collective.
 // The exchange unit is the same packed record as the multi-process path (hdb_packed_bytes); it is 1.2 KB per shard at
-// nq=1, k=100, so the step is latency-bound and needs no collective library in-process.  Queries whose sampled
-// threshold failed on any shard are re-run on every shard through the exact selection and merged again.
+// nq=1, k=100, so the step is latency-bound and needs no collective library in-process.
+// Shards that share a device (a test layout) must not run two single-launch pipelines at once -- each wants every CU for its
+// in-kernel exchange -- so their calls take the multi-kernel pipeline; the shards' own handles keep their options.
 // ================================================================================================
 #include <thread>
 #include <mutex>
@@ -992,88 +997,99 @@ struct hdb_group {
     int parts = 0;
     std::vector<hdb_index*> ix;
     std::vector<hipStream_t> st;
-    std::vector<hipEvent_t> ev;
     std::vector<void*> qdev;
     std::vector<size_t> qcap;
-    int merge_dev = 0;
-    hipStream_t merge_st = nullptr;
+    std::vector<char> shared_dev;                         // shard p shares its device with another shard of the group
     char* gather = nullptr; size_t gather_bytes = 0;     // pinned + portable host memory: parts records
-    char* out = nullptr; size_t out_bytes = 0;           // pinned + portable host memory: the merged record
+    char* qpin = nullptr; size_t qpin_bytes = 0;         // pinned + portable host memory: the queries of the current call
     // workers
     std::vector<std::thread> th;
     std::mutex mu;
     std::condition_variable cv_job, cv_done;
-    uint64_t job_seq = 0;
-    int pending = 0;
-    bool stop = false;
-    // current job (written under mu before job_seq moves)
-    const void* host_Q = nullptr; size_t q_bytes = 0;
-    int nq = 0, k = 0, metric = 0; bool exact = false; size_t stride = 0;
+    std::atomic<uint64_t> job_seq{0};
+    std::atomic<int> pending{0};
+    std::atomic<bool> stop{false};
+    // current job (written before job_seq moves)
+    size_t q_bytes = 0;
+    int nq = 0, k = 0, metric = 0; size_t stride = 0;
     std::vector<int> rc;
     std::vector<std::string> err;
 };
+
+static constexpr long HDB_GROUP_SPIN_US = 200;           // how long a worker / the caller spins before it parks
 
 static void group_worker(hdb_group* g, int p) {
     (void)hipSetDevice(g->ix[p]->device);
     uint64_t seen = 0;
     for (;;) {
-        {
-            std::unique_lock<std::mutex> lk(g->mu);
-            g->cv_job.wait(lk, [&] { return g->stop || g->job_seq != seen; });
-            if (g->stop) return;
-            seen = g->job_seq;
+        // wait for a job: spin for a short window (a query stream keeps the workers hot), then park
+        bool got = false;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0;; ++spins) {
+            if (g->stop.load(std::memory_order_acquire)) return;
+            if (g->job_seq.load(std::memory_order_acquire) != seen) { got = true; break; }
+            __builtin_ia32_pause();
+            if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(HDB_GROUP_SPIN_US)) break;
         }
+        if (!got) {
+            std::unique_lock<std::mutex> lk(g->mu);
+            g->cv_job.wait(lk, [&] { return g->stop.load(std::memory_order_acquire) || g->job_seq.load(std::memory_order_acquire) != seen; });
+            if (g->stop.load(std::memory_order_acquire)) return;
+        }
+        seen = g->job_seq.load(std::memory_order_acquire);
         int rc = HDB_OK;
         std::string msg;
         hdb_index* ix = g->ix[p];
         hipStream_t st = g->st[p];
-        hipError_t e = hipSuccess;
-        if (g->q_bytes > g->qcap[p]) {
-            if (g->qdev[p]) { (void)hipStreamSynchronize(st); (void)hipFree(g->qdev[p]); g->qdev[p] = nullptr; g->qcap[p] = 0; }
-            e = hipMalloc(&g->qdev[p], g->q_bytes * 2);
-            if (e == hipSuccess) g->qcap[p] = g->q_bytes * 2;
-        }
-        if (e == hipSuccess) e = hipMemcpyAsync(g->qdev[p], g->host_Q, g->q_bytes, hipMemcpyHostToDevice, st);
-        if (e != hipSuccess) { rc = HDB_ERR_HIP; msg = std::string("hdb_group: query upload: ") + hipGetErrorString(e); }
-        if (rc == HDB_OK) {
+        if (ix->n > 0) {
+            const void* dq = g->qpin;                                // up to four queries: the kernels read the pinned staging buffer
+            if (g->nq > 4) {
+                hipError_t e = hipSuccess;
+                if (g->q_bytes > g->qcap[p]) {
+                    if (g->qdev[p]) { (void)hipStreamSynchronize(st); (void)hipFree(g->qdev[p]); g->qdev[p] = nullptr; g->qcap[p] = 0; }
+                    e = hipMalloc(&g->qdev[p], g->q_bytes * 2);
+                    if (e == hipSuccess) g->qcap[p] = g->q_bytes * 2;
+                }
+                if (e == hipSuccess) e = hipMemcpyAsync(g->qdev[p], g->qpin, g->q_bytes, hipMemcpyHostToDevice, st);
+                if (e != hipSuccess) { rc = HDB_ERR_HIP; msg = std::string("hdb_group: query upload: ") + hipGetErrorString(e); }
+                dq = g->qdev[p];
+            }
+            if (rc == HDB_OK) {
+                const int64_t saved = ix->use_fused;
+                if (g->shared_dev[p]) ix->use_fused = 0;             // for this call only (one call in flight per handle)
+                rc = hdb_topk_host(ix, dq, g->nq, g->k, g->metric, g->gather + (size_t)p * g->stride, st);
+                ix->use_fused = saved;
+                if (rc != HDB_OK) msg = hdb_last_error();
+            }
+        } else {                                                     // an empty shard contributes padding
             char* rec = g->gather + (size_t)p * g->stride;
-            int64_t* d_idx = reinterpret_cast<int64_t*>(rec);
-            float* d_sc = reinterpret_cast<float*>(rec + (size_t)g->nq * g->k * 8);
-            int32_t* d_st = reinterpret_cast<int32_t*>(rec + (size_t)g->nq * g->k * 12);
-            rc = g->exact ? hdb_topk_exact(ix, g->qdev[p], g->nq, g->k, g->metric, d_idx, d_sc, d_st, st)
-                          : hdb_topk(ix, g->qdev[p], g->nq, g->k, g->metric, d_idx, d_sc, d_st, st);
-            if (rc != HDB_OK) msg = hdb_last_error();
+            int64_t* ri = reinterpret_cast<int64_t*>(rec);
+            float* rs = reinterpret_cast<float*>(rec + (size_t)g->nq * g->k * 8);
+            int32_t* rst = reinterpret_cast<int32_t*>(rec + (size_t)g->nq * g->k * 12);
+            for (size_t i = 0; i < (size_t)g->nq * g->k; ++i) { ri[i] = -1; rs[i] = -INFINITY; }
+            for (int q = 0; q < g->nq; ++q) rst[q] = 0;
         }
-        if (rc == HDB_OK) {              // the record is in the pinned gather buffer once this shard's stream has drained
-            e = hipStreamSynchronize(st);
-            if (e != hipSuccess) { rc = HDB_ERR_HIP; msg = std::string("hdb_group: synchronize: ") + hipGetErrorString(e); }
-        }
-        {
-            std::lock_guard<std::mutex> lk(g->mu);
-            g->rc[p] = rc; g->err[p] = msg;
-            if (--g->pending == 0) g->cv_done.notify_all();
+        g->rc[p] = rc; g->err[p] = msg;
+        if (g->pending.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+            { std::lock_guard<std::mutex> lk(g->mu); }
+            g->cv_done.notify_all();
         }
     }
 }
 
 extern "C" void hdb_group_destroy(hdb_group* g) {
     if (!g) return;
-    {
-        std::lock_guard<std::mutex> lk(g->mu);
-        g->stop = true;
-    }
+    g->stop.store(true, std::memory_order_release);
+    { std::lock_guard<std::mutex> lk(g->mu); }
     g->cv_job.notify_all();
     for (auto& t : g->th) if (t.joinable()) t.join();
     for (int p = 0; p < (int)g->st.size(); ++p) {
         (void)hipSetDevice(g->ix[p]->device);
         if (g->st[p]) { (void)hipStreamSynchronize(g->st[p]); (void)hipStreamDestroy(g->st[p]); }
-        if (p < (int)g->ev.size() && g->ev[p]) (void)hipEventDestroy(g->ev[p]);
         if (p < (int)g->qdev.size() && g->qdev[p]) (void)hipFree(g->qdev[p]);
     }
-    (void)hipSetDevice(g->merge_dev);
-    if (g->merge_st) { (void)hipStreamSynchronize(g->merge_st); (void)hipStreamDestroy(g->merge_st); }
     if (g->gather) (void)hipHostFree(g->gather);
-    if (g->out) (void)hipHostFree(g->out);
+    if (g->qpin) (void)hipHostFree(g->qpin);
     delete g;
 }
 
@@ -1088,52 +1104,20 @@ extern "C" int hdb_group_create(hdb_group** out, hdb_index* const* shards, int32
     hdb_group* g = new hdb_group();
     g->parts = parts;
     g->ix.assign(shards, shards + parts);
-    g->st.assign(parts, nullptr); g->ev.assign(parts, nullptr); g->qdev.assign(parts, nullptr); g->qcap.assign(parts, 0);
+    g->st.assign(parts, nullptr); g->qdev.assign(parts, nullptr); g->qcap.assign(parts, 0);
     g->rc.assign(parts, 0); g->err.assign(parts, std::string());
-    g->merge_dev = shards[0]->device;
+    g->shared_dev.assign(parts, 0);
+    for (int p = 0; p < parts; ++p)
+        for (int r = 0; r < parts; ++r)
+            if (r != p && g->ix[r]->device == g->ix[p]->device) g->shared_dev[p] = 1;
     hipError_t e = hipSuccess;
     for (int p = 0; p < parts && e == hipSuccess; ++p) {
         e = hipSetDevice(g->ix[p]->device);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->st[p], hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev[p], hipEventDisableTiming);
     }
-    if (e == hipSuccess) e = hipSetDevice(g->merge_dev);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->merge_st, hipStreamNonBlocking);
     if (e != hipSuccess) { hdb_group_destroy(g); return fail(HDB_ERR_HIP, std::string("hdb_group_create: ") + hipGetErrorString(e)); }
-    // Two shards on ONE device would launch two single-launch pipelines at once, each wanting every CU for its in-kernel
-    // exchange: they could block each other until the spin timeout.  Such shards (a test layout) use the multi-kernel pipeline.
-    for (int p = 0; p < parts; ++p)
-        for (int r = 0; r < parts; ++r)
-            if (r != p && g->ix[r]->device == g->ix[p]->device) g->ix[p]->use_fused = 0;
     for (int p = 0; p < parts; ++p) g->th.emplace_back(group_worker, g, p);
     *out = g;
-    return HDB_OK;
-}
-
-// one round over all shards: wake the workers, wait until every pipeline is ENQUEUED, then merge on the merge stream
-static int group_round(hdb_group* g, const void* host_Q, size_t q_bytes, int nq, int k, int metric, bool exact, char* merged) {
-    {
-        std::lock_guard<std::mutex> lk(g->mu);
-        g->host_Q = host_Q; g->q_bytes = q_bytes; g->nq = nq; g->k = k; g->metric = metric; g->exact = exact;
-        g->stride = (size_t)hdb_packed_bytes(nq, k);
-        g->pending = g->parts;
-        ++g->job_seq;
-    }
-    g->cv_job.notify_all();
-    {
-        std::unique_lock<std::mutex> lk(g->mu);
-        g->cv_done.wait(lk, [&] { return g->pending == 0; });
-    }
-    for (int p = 0; p < g->parts; ++p)
-        if (g->rc[p] != HDB_OK) {
-            for (int r = 0; r < g->parts; ++r) { (void)hipSetDevice(g->ix[r]->device); (void)hipStreamSynchronize(g->st[r]); }
-            return fail(g->rc[p], "shard " + std::to_string(p) + ": " + g->err[p]);
-        }
-    // every shard's record sits in host memory (each worker drained its stream): merge on the host -- no merge launch, no
-    // second synchronisation
-    std::vector<const char*> recs((size_t)g->parts);
-    for (int p = 0; p < g->parts; ++p) recs[p] = g->gather + (size_t)p * g->stride;
-    merge_host_records(recs.data(), g->parts, nq, k, merged);
     return HDB_OK;
 }
 
@@ -1149,27 +1133,38 @@ static int group_pinned(char** buf, size_t* have, size_t need) {
 extern "C" int hdb_group_topk_host(hdb_group* g, const void* host_Q, int32_t nq, int32_t k, int metric, void* host_record) {
     if (!g || !host_Q || !host_record) return fail(HDB_ERR_ARG, "hdb_group_topk_host: null argument");
     if (nq <= 0 || k <= 0) return fail(HDB_ERR_ARG, "hdb_group_topk_host: nq and k must be positive");
-    if ((int64_t)g->parts * k > HDB_CAND_CAP) return fail(HDB_ERR_UNSUPPORTED, "hdb_group_topk_host: parts*k exceeds 8192");
     const size_t bytes = (size_t)hdb_packed_bytes(nq, k);
     const size_t qelem = g->ix[0]->dtype == HDB_F64 ? 8 : 4;
-    const size_t q_row = (size_t)g->ix[0]->d * qelem;
-    HIP_TRY(hipSetDevice(g->merge_dev));
-    for (int p = 0; p < g->parts; ++p) { HIP_TRY(hipSetDevice(g->ix[p]->device)); HIP_TRY(hipStreamSynchronize(g->st[p])); }   // buffers may be re-sized
-    HIP_TRY(hipSetDevice(g->merge_dev));
-    int rc = group_pinned(&g->gather, &g->gather_bytes, bytes * g->parts); if (rc) return rc;
-    rc = group_pinned(&g->out, &g->out_bytes, bytes); if (rc) return rc;
-    rc = group_round(g, host_Q, q_row * nq, nq, k, metric, false, g->out); if (rc) return rc;
-    memcpy(host_record, g->out, bytes);
-    int32_t* h_st = reinterpret_cast<int32_t*>(static_cast<char*>(host_record) + (size_t)nq * k * 12);
-    std::vector<int> bad;
-    for (int q = 0; q < nq; ++q) if (h_st[q] & (HDB_Q_UNDERFLOW | HDB_Q_OVERFLOW)) bad.push_back(q);
-    // rare: a shard's sampled threshold failed -> that query goes through the exact selection on EVERY shard, merged again
-    for (int q : bad) {
-        rc = group_round(g, static_cast<const char*>(host_Q) + (size_t)q * q_row, q_row, 1, k, metric, true, g->out); if (rc) return rc;
-        char* hr = static_cast<char*>(host_record);
-        memcpy(hr + (size_t)q * k * 8, g->out, (size_t)k * 8);
-        memcpy(hr + (size_t)nq * k * 8 + (size_t)q * k * 4, g->out + (size_t)k * 8, (size_t)k * 4);
-        h_st[q] = *reinterpret_cast<int32_t*>(g->out + (size_t)k * 12);
+    const size_t q_bytes = (size_t)g->ix[0]->d * qelem * nq;
+    if (bytes * g->parts > g->gather_bytes || q_bytes > g->qpin_bytes) {      // (no call is in flight: the previous one returned)
+        HIP_TRY(hipSetDevice(g->ix[0]->device));
+        int rc = group_pinned(&g->gather, &g->gather_bytes, bytes * g->parts); if (rc) return rc;
+        rc = group_pinned(&g->qpin, &g->qpin_bytes, q_bytes); if (rc) return rc;
     }
+    memcpy(g->qpin, host_Q, q_bytes);
+    g->q_bytes = q_bytes; g->nq = nq; g->k = k; g->metric = metric; g->stride = bytes;
+    g->pending.store(g->parts, std::memory_order_release);
+    g->job_seq.fetch_add(1, std::memory_order_acq_rel);
+    { std::lock_guard<std::mutex> lk(g->mu); }
+    g->cv_job.notify_all();
+    // wait for the shards: spin (a shard-sized call takes ~0.2 ms), then park
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        bool done = false;
+        for (unsigned spins = 0;; ++spins) {
+            if (g->pending.load(std::memory_order_acquire) == 0) { done = true; break; }
+            __builtin_ia32_pause();
+            if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(5)) break;
+        }
+        if (!done) {
+            std::unique_lock<std::mutex> lk(g->mu);
+            g->cv_done.wait(lk, [&] { return g->pending.load(std::memory_order_acquire) == 0; });
+        }
+    }
+    for (int p = 0; p < g->parts; ++p)
+        if (g->rc[p] != HDB_OK) return fail(g->rc[p], "shard " + std::to_string(p) + ": " + g->err[p]);
+    std::vector<const char*> recs((size_t)g->parts);
+    for (int p = 0; p < g->parts; ++p) recs[p] = g->gather + (size_t)p * g->stride;
+    merge_host_records(recs.data(), g->parts, nq, k, host_record);
     return HDB_OK;
 }

@@ -568,11 +568,11 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                             }
                             if (may_skip || !first) break;
                             if (spin_expired(sweep_t0)) {
+                                // giving up ends the exchange for EVERY query of the call (the loop skips this wave's other
+                                // query from here on): a threshold left at NaN would keep wave 0 parking for good
                                 gave_up = true;
-                                if (lane == 0) {
-                                    hdb_lds_st32(qpar_addr + (unsigned int)(2 * HDB_FUSED_MAXQ + q) * 4u, INFINITY);
-                                    atomicOr(&f.ctl[1], 1u);
-                                }
+                                if (lane < nq) hdb_lds_st32(qpar_addr + (unsigned int)(2 * HDB_FUSED_MAXQ + lane) * 4u, INFINITY);
+                                if (lane == 0) atomicOr(&f.ctl[1], 1u);
                                 break;
                             }
                             __builtin_amdgcn_s_sleep(2);
@@ -656,11 +656,9 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                         }
                         if (may_skip) break;             // try again next round; this round's tile gets parked
                         if (spin_expired(sweep_t0)) {    // too few workgroups answered within the timeout: give up (host falls back)
-                            gave_up = true;
-                            if (lane == 0) {
-                                hdb_lds_st32(qpar_addr + (unsigned int)(2 * HDB_FUSED_MAXQ + q) * 4u, INFINITY);
-                                atomicOr(&f.ctl[1], 1u);
-                            }
+                            gave_up = true;                  // for every query of the call, see above
+                            if (lane < nq) hdb_lds_st32(qpar_addr + (unsigned int)(2 * HDB_FUSED_MAXQ + lane) * 4u, INFINITY);
+                            if (lane == 0) atomicOr(&f.ctl[1], 1u);
                             break;
                         }
                         __builtin_amdgcn_s_sleep(2);
@@ -699,7 +697,11 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                     }
                 }
                 const int u_own_p = hdb_owned_row(l16);
-                if (!thr_known) {                    // parking: keep the comparable values of this tile, filter them later
+                if (!thr_known && npend >= pend_max) {
+                    // the parking area is full and no threshold has come (the selector holds the round until one exists, so
+                    // this means the exchange was abandoned): drop the tile under the abort word -- the host re-runs the call
+                    if (lane == 0) atomicOr(&f.ctl[1], 1u);
+                } else if (!thr_known) {             // parking: keep the comparable values of this tile, filter them later
 #pragma unroll
                     for (int q = 0; q < VQ; ++q)
 #pragma unroll
@@ -811,7 +813,9 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                     }
                 }
                 const unsigned int pslot = (unsigned int)(rl * R + 4 * h) * 4u;
-                if (PARK && !thr_known) {            // parking: keep the comparable values of this tile, filter them later
+                if (PARK && !thr_known && npend >= pend_max) {
+                    if (lane == 0) atomicOr(&f.ctl[1], 1u);      // parking area full, exchange abandoned: drop the tile under the abort word
+                } else if (PARK && !thr_known) {     // parking: keep the comparable values of this tile, filter them later
                     if (q_ok) {
 #pragma unroll
                         for (int rt = 0; rt < RT; ++rt) hdb_lds_st128(pbuf_addr + (unsigned int)npend * pend_stride + pslot + (unsigned int)rt * 64u, acc[rt]);

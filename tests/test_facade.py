@@ -464,6 +464,29 @@ def test_single_process_group_two_logical_shards_on_one_gpu():
     finally:
         one.close()
         two.close()
+    # eight logical shards, and a k beyond what the device merge kernels take (8 x 2048 > 8192: the group merges on the host)
+    n8 = 200_000
+    V8 = rng.standard_normal((n8, 128)).astype(np.float32).astype(np.float16)
+    Q8 = rng.standard_normal((3, 128)).astype(np.float32)
+    one = ranking.register_vectors(V8)
+    eight = ranking.register_vectors(V8, devices=[0] * 8)
+    try:
+        assert len(eight.index.shards) == 8 and eight.index.shards[7].row_base == 175_000
+        for metric in ("cosine_similarity", "euclidean_metric", "hamming_distance"):
+            for k in (100, 2048, 3000):
+                ai, as_ = one.index.topk(Q8, k, METRIC_IDS[metric])
+                bi, bs = eight.index.topk(Q8, k, METRIC_IDS[metric])
+                assert np.array_equal(ai, bi) and np.array_equal(as_, bs), (metric, k)
+        assert all(s_.stat("fused") == 0 for s_ in eight.index.shards)          # shards that share a device: multi-kernel pipeline ...
+        eight.index.shards[0].topk(Q8[:1], 10, METRIC_IDS["cosine_similarity"])
+        assert eight.index.shards[0].stat("fused") != 0                          # ... for group calls only: the handle keeps its options
+        for _ in range(50):                                                        # a query stream: workers stay hot, nothing leaks
+            bi, bs = eight.index.topk(Q8[:1], 100, METRIC_IDS["dot_product"])
+        ai, as_ = one.index.topk(Q8[:1], 100, METRIC_IDS["dot_product"])
+        assert np.array_equal(ai, bi) and np.array_equal(as_, bs)
+    finally:
+        one.close()
+        eight.close()
     # the facade on two shards: filters, double recency, append (goes behind the last shard), removal + compaction
     docs = _docs(2000)
     W = rng.standard_normal((2000, 64)).astype(np.float32)
