@@ -51,6 +51,8 @@ int hdb_mfma_tile_rows(int dtype, int d);
 int hdb_launch_mfma_scan(const ScanArgs* args, int dtype, int mode, int nq_launch, const void* q16, const float* sqnorm,
                          const float* qsq, const float* qscl, int max_blocks, int variant, void* stream, const BatchArgs* f);
 int hdb_mfma_batch_capacity(int dtype, int d);
+int hdb_bits_fused_supported(int metric, int nq, int W, uint32_t kk);
+int hdb_launch_bits_fused(const BitsArgs* args, int jaccard, int max_blocks, void* stream);
 size_t hdb_mfma_batch_ctl_bytes(int wgs);
 int hdb_mfma_fused_supported(int dtype, int d, int metric, int nq, uint32_t kk);
 size_t hdb_mfma_fused_ctl_bytes(void);
@@ -336,7 +338,7 @@ extern "C" int hdb_set_option(hdb_index* ix, const char* name, int64_t value) {
     else if (!strcmp(name, "use_mfma")) ix->use_mfma = value;
     else if (!strcmp(name, "exact_bytes")) ix->exact_bytes = std::max<int64_t>(1 << 20, value);
     else if (!strcmp(name, "finalize_threads")) { if (value == 256 || value == 512 || value == 1024) ix->finalize_threads = value; }
-    else if (!strcmp(name, "mfma_variant")) { if (value == 16 || value == 32) ix->mfma_variant = value; }
+    else if (!strcmp(name, "mfma_variant")) { if (value == 16 || value == 32 || value == 64) ix->mfma_variant = value; }
     else if (!strcmp(name, "host_direct")) ix->host_direct = value;
     else if (!strcmp(name, "use_fused")) ix->use_fused = value;
     else if (!strcmp(name, "use_batch1")) ix->use_batch1 = value;
@@ -589,10 +591,16 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     // the MFMA scan multiplies with fp16 queries: written by the same kernel (pearson converts its centred copy later)
     const bool f16_queries = mfma && ix->dtype == HDB_F16;          // fp32 matrices multiply with the float32 queries as they are
     const bool q16_in_prep = f16_queries && !is_pearson && !full_sort;
-    if (!fused && !batch1) LAUNCH_TRY(hdb_launch_qprep(dev_Q, nq, ix->d, f64, qinv, qsq, qnan, q16_in_prep ? q16 : nullptr, qscl, st));
+    // (one query on a large matrix stays with the six launches: their 32-waves-per-CU scan streams 5-7 % faster than the scan
+    // inside the 16-wave persistent workgroups -- 124 vs 132 us at N=10M, 63 vs 66 at 1.25M, but 52 vs 46 at 250k rows; two to
+    // four queries: 200 vs 140 us at N=10M, profiles/r3_bits_single_launch_vs_six.txt)
+    const bool bits1_pre = ix->use_fused && ix->bits_fused && is_ham && !exact && !small && !full_sort && !f64 && dev_status != nullptr &&
+                           hdb_bits_fused_supported(metric, 1, W, kk) && (nq >= 2 || n < 1000000 || ix->bits_fused == 2);
+                           // (the single launch prepares its queries itself; bits_fused = 2 forces it)
+    if (!fused && !batch1 && !bits1_pre) LAUNCH_TRY(hdb_launch_qprep(dev_Q, nq, ix->d, f64, qinv, qsq, qnan, q16_in_prep ? q16 : nullptr, qscl, st));
     if (is_ham) {
         rc = ensure_bits(ix, st); if (rc) return rc;
-        LAUNCH_TRY(hdb_launch_qsign(dev_Q, nq, ix->d, f64, W, qbits, st));
+        if (!bits1_pre) LAUNCH_TRY(hdb_launch_qsign(dev_Q, nq, ix->d, f64, W, qbits, st));
     }
     const void* Qeff = dev_Q;
     int metric_eff = metric;
@@ -674,6 +682,37 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
         prof_begin(ix, st);
         LAUNCH_TRY(hdb_launch_mfma_fused(&a, ix->dtype, &fa, (int)ix->max_blocks, st));
         prof_end(ix, st);
+        return HDB_OK;
+    }
+    // 1-4 hamming / jaccard queries per launch: prep, sample, threshold, the pass over the sign bits and the final sort in ONE
+    // kernel (hdb_bits_fused.hip); larger batches go through it four queries at a time (as the multi-kernel scan re-reads the bits)
+    const bool bits1 = bits1_pre;
+    if (bits1) {
+        if (!ix->bctl) {
+            const size_t cb = hdb_mfma_batch_ctl_bytes(hdb_cu_count());
+            HIP_TRY(hipMalloc((void**)&ix->bctl, cb));
+            HIP_TRY(hipMemset(ix->bctl, 0, cb));
+        }
+        ix->st_sample_rows = s_rows; ix->st_sample_m = m; ix->st_chunks = 0; ix->st_path = 1; ix->st_mfma = 0; ix->st_fused = 3;
+        for (int q0 = 0; q0 < nq; q0 += 4) {
+            const int cq = std::min(4, nq - q0);
+            ix->st_chunks++;
+            BitsArgs ba; memset(&ba, 0, sizeof(ba));
+            ba.bits = ix->bits; ba.npad = ix->bits_npad; ba.W = W; ba.n = n; ba.d = ix->d;
+            ba.Qraw = static_cast<const float*>(dev_Q) + (size_t)q0 * ix->d; ba.nq = cq;
+            ba.ntiles = (n + 15) / 16; ba.s_tiles = s_tiles; ba.s_stride = s_stride;
+            ba.bias = ix->bias; ba.mask = ix->mask;
+            ix->fused_epoch = (ix->fused_epoch + 1) & 0x7FFFFFFFu;
+            if (ix->fused_epoch == 0) ix->fused_epoch = 1;
+            ba.epoch = ix->fused_epoch;
+            ba.timeout_ticks = (uint32_t)std::min<int64_t>(ix->fused_timeout_us * 100, 0x7FFFFFFF);
+            ba.ctl = reinterpret_cast<uint32_t*>(ix->bctl);
+            ba.cand = cand; ba.cap = HDB_CAND_CAP; ba.k = (uint32_t)k; ba.kk = kk; ba.row_base = ix->row_base;
+            ba.idx_out = dev_idx + (int64_t)q0 * k; ba.score_out = dev_score + (int64_t)q0 * k; ba.status = dev_status + q0;
+            prof_begin(ix, st);
+            LAUNCH_TRY(hdb_launch_bits_fused(&ba, metric == HDB_JACCARD ? 1 : 0, (int)ix->max_blocks, st));
+            prof_end(ix, st);
+        }
         return HDB_OK;
     }
     if (batch1) {

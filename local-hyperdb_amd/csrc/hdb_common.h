@@ -86,6 +86,20 @@ struct BatchArgs {
     int64_t* idx_out; float* score_out; int32_t* status;
 };
 
+// Arguments of the single-launch top-k of the bit metrics (hdb_bits_fused.hip): 1-4 hamming / jaccard queries in one launch.
+struct BitsArgs {
+    const uint32_t* bits; int64_t npad; int32_t W;
+    int64_t n; int32_t d;
+    const float* Qraw; int32_t nq;
+    int64_t ntiles, s_tiles, s_stride;          // 16-row tiles
+    const float* bias; const uint8_t* mask;
+    uint32_t epoch, timeout_ticks;
+    uint32_t* ctl;                              // the control block of the batched single launch (HDB_BATCH_* layout)
+    unsigned long long* cand; uint32_t cap, k, kk;
+    int64_t row_base;
+    int64_t* idx_out; float* score_out; int32_t* status;
+};
+
 // ---- fp16 copy of a query for the matrix pipe ----------------------------------------------------------
 // Power-of-two scale that puts the largest magnitude of a query in [2^14, 2^15): an fp32 element above 65504 would
 // otherwise become inf in fp16 and one below 6e-5 a subnormal.  Exact, and undone for free in the kernel epilogue

@@ -126,7 +126,7 @@ extern "C" int hdb_launch_mfma_scan_f16_wide(const ScanArgs* args, int mode, int
 // workgroup per CU at most (the in-kernel exchange needs the grid co-resident)
 extern "C" int hdb_launch_mfma_scan(const ScanArgs* args, int dtype, int mode, int nq_launch, const void* q16, const float* sqnorm,
                                     const float* qsq, const float* qscl, int max_blocks, int variant, void* stream, const BatchArgs* f) {
-    const int g_mfma_variant = variant == 32 ? 32 : 16;
+    const int g_mfma_variant = variant == 32 ? 32 : variant == 64 ? 64 : 16;
     const ScanArgs& a = *args;
     hipStream_t st = (hipStream_t)stream;
     if (a.mask) return (int)hipErrorNotSupported;

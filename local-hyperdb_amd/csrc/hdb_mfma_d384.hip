@@ -10,6 +10,8 @@ extern "C" int hdb_launch_mfma_scan_f16_d384(const ScanArgs* args, int mode, int
     // more than 128 queries: 16 = 16x16x32 with two query tiles per wave (default: the same FLOPs and LDS traffic as the
     // 32x32x16 form, but the chip holds a higher clock on this shape: 1.78-1.85 ms against 2.07-2.25 ms for N=10M, Q=256),
     // 32 = 32x32x16 with one query tile per wave (kept for A/B measurements; hdb_set_option(ix, "mfma_variant", 16 | 32))
+    // 64 = the four-wave measurement variant (64 queries per wave, 256-thread workgroups; filter pass, dot product, no bias)
+    if (variant == 64 && mode == 1 && a.metric == HDB_DOT && !a.bias) return launch_four_waves<_Float16, 16, 4, 384, 64>(a, q16, qscl, nq_launch, blocks, st);
     if (nq_launch > 128 && variant == 32) return launch_mode<_Float16, 32, 1, 384, 64>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st, f);
     if (nq_launch > 128) return launch_mode<_Float16, 16, 2, 384, 64>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st, f);
     return launch_mode<_Float16, 16, 1, 384, 64>(a, mode, q16, sqnorm, qsq, qscl, nq_launch, blocks, st, f);

@@ -183,8 +183,11 @@ template <> struct MfmaShape<16, float> {
 //             the control block.
 // Every spin is bounded (s_memrealtime); a workgroup that gives up raises the abort word, which turns the statuses into
 // HDB_Q_UNDERFLOW so that the host re-runs those queries through the exact path.
-template <typename E, int MF, int QT, int D, int R, int RS, int MODE, int METRIC, bool HAS_BIAS>
-__global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __restrict__ q16,
+// NW: waves per workgroup.  8 is the product.  4 (MODE 1 only; tools/exp_4wave.py, profiles/r3_q256_four_waves.txt) is the
+// measurement variant "one wave per SIMD with up to 512 registers, 64 queries per wave": every wave stages a quarter of each tile
+// AND multiplies, the LDS fragment traffic per MFMA halves.
+template <typename E, int MF, int QT, int D, int R, int RS, int MODE, int METRIC, bool HAS_BIAS, int NW = 8>
+__global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* __restrict__ q16,
                                                        const float* __restrict__ aux0g, const float* __restrict__ qsq, const float* __restrict__ qscl,
                                                        int nq_end, BatchArgs f) {
     using Shape = MfmaShape<MF, E>;
@@ -205,6 +208,8 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
     constexpr int NAUX = (AUX0 ? 1 : 0) + (HAS_BIAS ? 1 : 0);            // per-row aux values, staged by every B wave
     constexpr int QPW = MF * QT;                // queries per wave (QT query tiles share every A fragment)
     static_assert(R % (MF * RS) == 0 && 8 % RS == 0 && R <= 64 && (R * CPR) % 256 == 0 && ROWB % 256 == 0 && PPL + NAUX <= 31, "tile geometry");
+    static_assert(NW == 8 || (NW == 4 && MODE == 1 && RS == 1), "four waves: the filter pass only");
+    static_assert(RS == 1 || RS == 2, "MODE 2 publishes 8 granules per query and workgroup: 4 lanes x 2 values, or 2 x 4 lanes x 1");
 
     constexpr bool FILT = MODE != 0;            // the pass over all rows filters against per-query thresholds
     constexpr bool ONE = MODE == 2;             // the whole call in this launch
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
 
     // ---- this wave's queries --------------------------------------------------------------------
     const int part = RS > 1 ? w % RS : 0;       // which row tiles of a stage this wave multiplies: part, part + RS, ...
-    const int qw0 = a.q0 + blockIdx.y * ((8 / RS) * QPW) + (w / RS) * QPW;
+    const int qw0 = a.q0 + blockIdx.y * ((NW / RS) * QPW) + (w / RS) * QPW;
     const bool wave_active = qw0 < nq_end;
     bool q_ok[QT];
     int ql[QT];
@@ -345,7 +350,8 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
     // ---- roles ----------------------------------------------------------------------------------------
     // Waves 0-3 ("A") and 4-7 ("B") are the two waves of each SIMD.  B runs its threshold epilogue one tile
     // late so that the two waves of a SIMD do not reach MFMA phase, epilogue and barrier in lock-step.
-    const bool grpB = w >= 4;
+    const bool grpB = NW == 4 || w >= 4;          // the waves that stage (all four of a four-wave workgroup)
+    const bool defer = NW == 4 ? w >= 2 : w >= 4;  // ... and the ones whose threshold epilogue runs one tile late
     HDB_BSTAMP(1);
     // B also stages every tile (see the note on staging roles at the top of this file); with up to 4*MF*QT queries in a
     // pass the B waves have no queries and do nothing else.
@@ -436,7 +442,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
     // multiplies for a quarter of a round; waves 4-7, which stage, never wait for the counter.  The request goes out LOOK
     // rounds (~3 us of streaming, the counter answers in ~1.5 us) before the chunk is needed; the answer is handed over
     // through LDS.
-    const bool heavy = (nq_end - (a.q0 + (int)blockIdx.y * ((8 / RS) * QPW))) > (4 / RS) * QPW;    // all eight waves multiply
+    const bool heavy = NW == 4 || (nq_end - (a.q0 + (int)blockIdx.y * ((8 / RS) * QPW))) > (4 / RS) * QPW;    // all waves multiply
     const int64_t G = gstep, bidx = blockIdx.x;
     // Measured (10 M rows, 8-64 queries, static -> dynamic): d=768 2.29 -> 2.18 ms, d=1536 (2.5 M rows) 1.149 -> 1.109,
     // d=512 (5 M) 0.775 -> 0.764, d=384 1.120 -> 1.106; but d=128 401 -> 438 us, d=256 (5 M) 394 -> 404, d=384 at 2.5 M rows
@@ -631,7 +637,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
 
         if (wave_active) {
             const int64_t row0 = rA;
-            if (FILT && grpB && i > 0) epi(acc, row0_prev);                // deferred epilogue of tile i-1
+            if (FILT && defer && i > 0) epi(acc, row0_prev);               // deferred epilogue of tile i-1
             // A fragments: LDS reads issued two k-steps ahead of the MFMAs that consume them.  The reads
             // and their counted waits are inline asm so that hipcc cannot sink a read next to its use
             // (it otherwise emits read, lgkmcnt(0), MFMA per step and exposes the LDS latency every step).
@@ -743,14 +749,14 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
                     }
                 }
             } else {
-                if (!grpB) epi(acc, row0);
+                if (!defer) epi(acc, row0);
                 else row0_prev = row0;
             }
         }
         st_cur = st_cur == 2 ? 0 : st_cur + 1;
         tA = tB; rA = rB; vA = vB; tB = tC; rB = rC; vB = vC;
     }
-    if (FILT && wave_active && grpB && had_tiles) epi(acc, row0_prev);     // the deferred epilogue of the last tile
+    if (FILT && wave_active && defer && had_tiles) epi(acc, row0_prev);    // the deferred epilogue of the last tile
     };
     if constexpr (!ONE) {
         run_pass(HdbIC<1>());
@@ -785,8 +791,15 @@ __global__ __launch_bounds__(512) void hdb_mfma_kernel(ScanArgs a, const E* __re
                 if (q_ok[qt]) {
                     const unsigned long long* dst = reinterpret_cast<const unsigned long long*>(f.ctl) + HDB_BATCH_GRAN_BYTE / 8 +
                                                     ((int64_t)ql[qt] * G + bidx) * 8 + (MF == 16 ? 2 * h : 4 * h);
-                    hdb_st128_sc1(dst, u32x4{hdb_f2key(top0[qt]), f.epoch, hdb_f2key(top1[qt]), f.epoch});
-                    if (MF == 32) hdb_st128_sc1(dst + 2, u32x4{1u, f.epoch, 1u, f.epoch});    // two lane groups per query: four granules stay empty
+                    if constexpr (RS == 2) {
+                        // two waves share a query group (each multiplies every other row tile): eight lanes per query, ONE granule
+                        // each -- the lane's largest value (both waves storing a pair to the same slots lost half of the sample:
+                        // the threshold came out low enough to overflow a list about once in a hundred calls)
+                        __hip_atomic_store((hdb_gu64*)(dst + part), ((unsigned long long)f.epoch << 32) | hdb_f2key(top0[qt]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        hdb_st128_sc1(dst, u32x4{hdb_f2key(top0[qt]), f.epoch, hdb_f2key(top1[qt]), f.epoch});
+                        if (MF == 32) hdb_st128_sc1(dst + 2, u32x4{1u, f.epoch, 1u, f.epoch});    // two lane groups per query: four granules stay empty
+                    }
                 }
             }
         }
@@ -1025,6 +1038,19 @@ static int launch_one(const ScanArgs& a, const void* q16, const float* aux0, con
     BatchArgs fa = BatchArgs();
     if (f) fa = *f;
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a, (const E*)q16, aux0, qsq, qscl, a.q0 + nq_launch, fa);
+    return (int)hipGetLastError();
+}
+
+// the four-wave measurement variant of the filter pass (dot product, no bias)
+template <typename E, int MF, int QT, int D, int R>
+static int launch_four_waves(const ScanArgs& a, const void* q16, const float* qscl, int nq_launch, int blocks, hipStream_t st) {
+    auto kern = hdb_mfma_kernel<E, MF, QT, D, R, 1, 1, 0, false, 4>;
+    const size_t lds = mfma_lds_bytes(R * D * (int)sizeof(E));
+    static unsigned long long attr_done = 0;
+    hipError_t e = hdb_lds_attr_once(reinterpret_cast<const void*>(kern), (int)lds, &attr_done);
+    if (e != hipSuccess) return (int)e;
+    const dim3 grid(blocks, (nq_launch + 4 * MF * QT - 1) / (4 * MF * QT));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a, (const E*)q16, nullptr, nullptr, qscl, a.q0 + nq_launch, BatchArgs());
     return (int)hipGetLastError();
 }
 

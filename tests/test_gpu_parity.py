@@ -1715,3 +1715,62 @@ def test_batched_single_launch_failure_paths(orc):
         assert int(st.abs().sum().item()) == 0 and torch.equal(fi, ei) and torch.equal(fs, es)
     finally:
         ix.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# 13. the single-launch pipeline of the bit metrics (hdb_bits_fused.hip): 1-4 hamming / jaccard queries per launch
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt,n,d", [(np.float16, 200_003, 384), (np.float32, 70_001, 100), (np.float16, 1_000_000, 768),
+                                     (np.float32, 8_193, 384), (np.float16, 300_000, 1536)])
+def test_bits_single_launch_equals_multi_kernel_and_exact(orc, dt, n, d):
+    """hamming / jaccard through ONE launch (stat 3) against the six-launch pipeline and the on-device exact selection, bit for
+    bit (integer scores, ties by ascending row): 1-7 queries (more than four go four at a time), bias, row mask, k up to 128,
+    d not a multiple of 32, a NaN query's status bit, and scores checked against the oracle's float64 integers."""
+    import torch
+    from hyperdb._native import GpuIndex, METRIC_IDS, Q_NAN
+    g = torch.Generator(device="cuda").manual_seed(n + d)
+    V = torch.randn((n, d), generator=g, device="cuda").to(torch.float16 if dt == np.float16 else torch.float32)
+    V[n - 1] = V[7]
+    ix = GpuIndex(V)
+    try:
+        bias = (torch.rand(n, generator=g, device="cuda") * 3.0).float()
+        mask = (torch.rand(n, generator=g, device="cuda") < 0.3).to(torch.uint8)
+        Q = torch.randn((7, d), generator=g, device="cuda").float()
+        Q[1] = V[n // 2].float()
+        for metric in ("hamming_distance", "jaccard_similarity"):
+            mid = METRIC_IDS[metric]
+            for setup in ("plain", "bias", "mask+bias"):
+                ix.set_bias(bias if "bias" in setup else None)
+                ix.set_row_mask(mask if "mask" in setup else None)
+                for nq, k in ((1, 100), (2, 1), (3, 128), (4, 37), (7, 10)):
+                    ix.set_option("use_fused", 1)
+                    fi, fs, fst = ix.topk_device(Q[:nq], k, mid)
+                    assert ix.stat("fused") == (3 if (nq >= 2 or n < 1_000_000) else 0) and ix.stat("path") == 1, (metric, setup, nq, k)
+                    ix.set_option("use_fused", 0)
+                    ui, us, ust = ix.topk_device(Q[:nq], k, mid)
+                    assert ix.stat("fused") == 0
+                    ei, es, _ = ix.topk_device(Q[:nq], k, mid, exact=True)
+                    for q in range(nq):
+                        if int(fst[q].item()) == 0:      # (coarse integer levels may overflow a list: those go through the exact path)
+                            assert torch.equal(fi[q], ei[q]) and torch.equal(fs[q], es[q]), (metric, setup, nq, k, q)
+                        assert int(fst[q].item()) == int(ust[q].item()) or int(fst[q].item()) == 0 or int(ust[q].item()) == 0
+                    ix.set_option("use_fused", 1)
+                    hi, hs = ix.topk(Q[:nq], k, mid)     # host entry: overflowing lists re-run inside
+                    assert np.array_equal(hi, ei.cpu().numpy()) and np.array_equal(hs, es.cpu().numpy()), (metric, setup, nq, k)
+            ix.set_bias(None); ix.set_row_mask(None)
+            idx, sc = ix.topk(Q[:2], 100, mid)
+            Vh = V.cpu().numpy()
+            for qi in range(2):
+                orc.check_topk(idx[qi], sc[qi], Vh, Q[qi].cpu().numpy(), metric, 100, tol=0.0 if metric == "hamming_distance" else 1e-6)
+            if metric == "hamming_distance":
+                assert idx[1][0] == n // 2 and sc[1][0] == d
+        ix.set_option("bits_fused", 2)                   # force the single launch for one query too
+        fi, fs, fst = ix.topk_device(Q[:1], 50, METRIC_IDS["hamming_distance"])
+        ei, es, _ = ix.topk_device(Q[:1], 50, METRIC_IDS["hamming_distance"], exact=True)
+        assert ix.stat("path") == 2 and (int(fst[0].item()) != 0 or (torch.equal(fi, ei) and torch.equal(fs, es)))
+        ix.set_option("bits_fused", 1)
+        Qn = Q[:3].clone(); Qn[2, 5] = float("nan")
+        _, _, st = ix.topk_device(Qn, 10, METRIC_IDS["hamming_distance"])
+        assert ix.stat("fused") == 3 and (int(st[2].item()) & Q_NAN) and not (int(st[0].item()) & Q_NAN)
+    finally:
+        ix.close()

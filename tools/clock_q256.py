@@ -31,6 +31,9 @@ V, lo, hi = bench.make_shard(n, d, torch.float16, 0, 1, dev)
 ix = GpuIndex(V)
 Q = bench.make_queries(q, d, torch.float16, dev)
 mid = METRIC_IDS['dot_product']
+import os
+if os.environ.get('HDB_Q256_PIPELINE'):            # "16" / "64": the five-kernel pipeline's filter pass with that MFMA variant
+    ix.set_option('use_fused', 0); ix.set_option('dyn_tiles', 0); ix.set_option('mfma_variant', int(os.environ['HDB_Q256_PIPELINE']))
 t_end = time.time() + 2.5
 calls = 0
 while time.time() < t_end:                      # >= 2 s of back-to-back launches before the launch that is read
@@ -79,13 +82,18 @@ def run(dst):
     res = {"workload": "N=10M d=384 fp16 Q=256 dot_product top-100, hdb_mfma_kernel<f16,16,2,384,64,1,1,0>",
            "method": "s_memtime / s_memrealtime stamps around the tile loop, diagnostic build (HDB_MFMA_CLOCK=1), "
                      ">= 2 s of back-to-back launches first; interleaved rounds of all variants in one job", "rounds": []}
+    runs = [(v, VARIANTS[v] + " (single launch, MODE 2 filter pass)", None) for v in VARIANTS]
+    runs += [(0, "five-kernel pipeline's filter pass: 8 waves x 32 queries (static tiles)", "16"),
+             (0, "five-kernel pipeline's filter pass: 4 waves x 64 queries, one wave per SIMD, 450 registers (measurement variant)", "64")]
     for rnd in range(2):
-        for v in VARIANTS:
+        for v, label, pipe in runs:
             env = dict(os.environ, HYPERDB_HIP_LIB=os.path.join(OUT, f'lib_{v}.so'))
+            if pipe:
+                env["HDB_Q256_PIPELINE"] = pipe
             r = subprocess.run([sys.executable, '-c', CHILD], env=env, cwd=ROOT, timeout=300, stderr=subprocess.DEVNULL, stdout=subprocess.PIPE, text=True)
             line = [x for x in r.stdout.splitlines() if x.startswith('{')]
             rec = json.loads(line[-1]) if line else {"error": r.stdout[-300:]}
-            rec.update(variant=VARIANTS[v], round=rnd)
+            rec.update(variant=label, round=rnd)
             res["rounds"].append(rec)
             print(rec, flush=True)
     json.dump(res, open(dst, 'w'), indent=1)
