@@ -51,6 +51,7 @@ int hdb_mfma_tile_rows(int dtype, int d);
 int hdb_launch_mfma_scan(const ScanArgs* args, int dtype, int mode, int nq_launch, const void* q16, const float* sqnorm,
                          const float* qsq, const float* qscl, int max_blocks, int variant, void* stream, const BatchArgs* f);
 int hdb_mfma_batch_capacity(int dtype, int d);
+int hdb_mfma_ksplit_slices(int dtype, int d);
 int hdb_bits_fused_supported(int metric, int nq, int W, uint32_t kk);
 int hdb_launch_bits_fused(const BitsArgs* args, int jaccard, int max_blocks, void* stream);
 size_t hdb_mfma_batch_ctl_bytes(int wgs);
@@ -131,7 +132,7 @@ struct hdb_index {
     int64_t host_direct = 1;          // hdb_topk_host: kernels write a pinned host record themselves (no D2H copy)
     int64_t dyn_tiles = 1;            // MFMA filter pass: hand tiles out from a counter (0: static split)
     int64_t dyn_min_mb = 16;          // ... for passes of at least this many MiB of V per workgroup
-    int64_t dyn_heavy = 1;            // ... also when all eight waves multiply
+    int64_t dyn_heavy = 0;            // ... also when all eight waves multiply (measured: 1.3-5 % slower at 256 queries, profiles/r3_q256_clock.json)
     int64_t host_poll = 1;            // hdb_topk_host + single-launch pipeline + pinned record: poll the status words instead of the stream
     int64_t use_fused = 1;            // 1-4 dot / cosine queries on an fp16 matrix: the whole call in ONE kernel (hdb_mfma_fused.h)
     int64_t use_batch1 = 1;           // 5+ queries (euclidean: 1+) on the matrix cores, k <= 128: the whole call in ONE launch per <= 256 queries (needs use_fused)
@@ -533,7 +534,9 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     if (!small && (int64_t)kk * 32 > n) exact = true;        // k is a large share of the rows: a sampled threshold cannot help
     // fp32 matrices: the VALU scan serves up to 4 queries in one pass at HBM speed; the fp32 MFMA scan (matrix-pipe
     // bound at 157 TFLOP/s) takes over where a second VALU pass would start
-    const int64_t min_q = ix->dtype == HDB_F32 ? std::max<int64_t>(ix->mfma_min_q, 5) : ix->mfma_min_q;
+    // (rows that need K slices -- float32 d >= 1024, fp16 d >= 2048 -- likewise: up to 4 queries are one VALU pass at HBM speed, the
+    // slices pay a second launch and the partial sums)
+    const int64_t min_q = (ix->dtype == HDB_F32 || hdb_mfma_ksplit_slices(ix->dtype, ix->d) > 0) ? std::max<int64_t>(ix->mfma_min_q, 5) : ix->mfma_min_q;
     const bool mfma = ix->use_mfma && !is_ham && !small && nq >= min_q &&
                       hdb_mfma_supported(ix->dtype, ix->d, is_pearson ? (int)HDB_COSINE : metric);
     // 1-4 dot / cosine queries, k <= 128: one launch does everything (hdb_mfma_fused.h; fp16 on the matrix cores,
@@ -561,6 +564,9 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     const int64_t ld_n = align_up((size_t)n, 4);
     int cq_max = batch1 ? bcap : 256;
     if (exact && !small) cq_max = (int)std::max<int64_t>(1, std::min<int64_t>(256, ix->exact_bytes / (ld_n * 4)));
+    // wide rows on the matrix cores go through K slices with a [query][rows] buffer of partial sums (hdb_mfma_ksplit.hip)
+    const bool ksplit = mfma && hdb_mfma_ksplit_slices(ix->dtype, ix->d) > 0;
+    if (ksplit && !small) cq_max = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(cq_max, 128), ix->exact_bytes / (ld_n * 4)));
     cq_max = std::min(cq_max, (int)nq);
 
     size_t need = 0;
@@ -573,6 +579,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     need += align_up((size_t)cq_max * 16, 256);                              // tie_info
     need += align_up((size_t)cq_max * HDB_CAND_CAP * 8, 256);                // cand
     need += align_up((size_t)cq_max * (exact && !small ? ld_n : ld_s) * 4, 256) + 4096;
+    if (ksplit) need += align_up((size_t)cq_max * ld_n * 4, 256);
     int rc = ensure_ws(ix, need);
     if (rc) return rc;
     Bump b(ix->ws, ix->ws_bytes);
@@ -586,6 +593,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     uint32_t* tie_info = b.take<uint32_t>((size_t)cq_max * 4);
     unsigned long long* cand = b.take<unsigned long long>((size_t)cq_max * HDB_CAND_CAP);
     float* sbuf = b.take<float>((size_t)cq_max * (exact && !small ? ld_n : ld_s));
+    float* kbuf = ksplit ? b.take<float>((size_t)cq_max * ld_n) : nullptr;
 
     const bool fused = fused_shape && !full_sort && m == 8;           // (no prep kernel either)
     // the MFMA scan multiplies with fp16 queries: written by the same kernel (pearson converts its centred copy later)
@@ -763,6 +771,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
         a.q0 = q0; a.bias = bias_eff; a.mask = mask_eff;
         a.thr = thr; a.cnt = cnt; a.cand = cand;
         a.ntiles = (n + tile_rows - 1) / tile_rows;
+        a.ks_partial_out = kbuf; a.ks_ld = ld_n;         // (K slices only; sample and exact passes index it by their own tile sequence)
 
         if (small) {
             LAUNCH_TRY(hdb_launch_fill_thr(thr, cnt, cq, -INFINITY, st));

@@ -77,9 +77,14 @@ __global__ __launch_bounds__(256) void hdb_rescore_euclid_kernel(unsigned long l
 // fp16: 16x16x32 MFMAs, 128 queries per pass (d <= 640 with more than 128 queries: two query tiles per wave, 256 per pass).
 // fp32: 16x16x4 MFMAs, 128 queries per pass; the matrix pipe (157 TFLOP/s) binds from ~16 queries on, so the VALU scan
 // keeps the calls of up to 4 queries (one pass at HBM speed) and this path takes the batches.
+extern "C" int hdb_mfma_ksplit_slices(int dtype, int d);
+extern "C" int hdb_launch_mfma_ksplit(const ScanArgs* args, int dtype, int mode, int nq_launch, const void* q, const float* sqnorm,
+                                      const float* qsq, const float* qscl, int blocks, void* stream);
+
 extern "C" int hdb_mfma_tile_rows(int dtype, int d) {
     const int elem = dtype == HDB_F16 ? 2 : dtype == HDB_F32 ? 4 : 0;
     if (!elem || d <= 0) return 0;
+    if (hdb_mfma_ksplit_slices(dtype, d) > 0) return 16;                  // wide rows: K slices of 16-row stages (hdb_mfma_ksplit.hip)
     const int row_bytes = d * elem;
     if (row_bytes % 256 != 0 || row_bytes > 3072) return 0;          // d <= 1536 (fp16) / 768 (fp32)
     if (dtype == HDB_F32 && d != 128 && d != 256 && d != 384 && d != 512 && d != 768) return 0;     // instantiated fp32 widths
@@ -90,7 +95,7 @@ extern "C" int hdb_mfma_tile_rows(int dtype, int d) {
 
 // queries ONE launch of the MFMA scan covers (grid.y == 1): what a single-launch (mode 2) call can take
 extern "C" int hdb_mfma_batch_capacity(int dtype, int d) {
-    if (hdb_mfma_tile_rows(dtype, d) <= 0) return 0;
+    if (hdb_mfma_tile_rows(dtype, d) <= 0 || hdb_mfma_ksplit_slices(dtype, d) > 0) return 0;      // (K slices: the multi-kernel pipeline)
     if (dtype == HDB_F32) return 128;
     return (d == 384 || d == 128 || d == 256 || d == 512 || d == 640) ? 256 : 128;      // two query tiles per wave (hdb_mfma_qt2.hip)
 }
@@ -138,6 +143,7 @@ extern "C" int hdb_launch_mfma_scan(const ScanArgs* args, int dtype, int mode, i
     if (max_blocks > 0 && max_blocks < blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
     if (mode == 2 && blocks > cus) blocks = cus;
+    if (hdb_mfma_ksplit_slices(dtype, a.d) > 0) return mode == 2 ? (int)hipErrorNotSupported : hdb_launch_mfma_ksplit(args, dtype, mode, nq_launch, q16, sqnorm, qsq, qscl, blocks, stream);
     if (dtype == HDB_F32) return hdb_launch_mfma_scan_f32(args, mode, nq_launch, q16, sqnorm, qsq, blocks, stream, f);
     if (dtype != HDB_F16) return (int)hipErrorNotSupported;
     if (nq_launch > 128 && hdb_mfma_qt2_supported(a.d) && g_mfma_variant != 32)

@@ -10,7 +10,7 @@ extern "C" int hdb_mfma_fused_supported(int dtype, int d, int metric, int nq, ui
     // registers) leave no room for the selectors' state: they stay in LDS, up to 2 queries (hdb_mfma_fused_wide.hip)
     // (d = 896: 28-KiB tiles of 28 k-steps keep the one multiplying wave busier than the stream: five kernels are 6 % faster)
     // (d = 128: 16-KiB tiles -- a round of this kernel costs ~1 us whatever the tile holds: 660 vs 400 us at 10 M rows)
-    const bool shape = (dtype == HDB_F16 && hdb_mfma_tile_rows(dtype, d) > 0 && d % 128 == 0 && d != 896 && d != 128) ||
+    const bool shape = (dtype == HDB_F16 && hdb_mfma_tile_rows(dtype, d) > 0 && d % 128 == 0 && d != 896 && d != 128 && d <= 1536) ||
                        (dtype == HDB_F32 && (d == 128 || d == 256 || d == 384 || d == 512 || d == 768));   // float32: VALU flavour
     // float32 queries live in registers as d/4 floats per lane group: 48 registers = 2 queries up to d = 384, 1 beyond
     const int maxq = dtype == HDB_F32 ? (d <= 384 ? 2 : 1) : (d <= 768 ? HDB_FUSED_MAXQ : 2);

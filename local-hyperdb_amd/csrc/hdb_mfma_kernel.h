@@ -186,7 +186,9 @@ template <> struct MfmaShape<16, float> {
 // NW: waves per workgroup.  8 is the product.  4 (MODE 1 only; tools/exp_4wave.py, profiles/r3_q256_four_waves.txt) is the
 // measurement variant "one wave per SIMD with up to 512 registers, 64 queries per wave": every wave stages a quarter of each tile
 // AND multiplies, the LDS fragment traffic per MFMA halves.
-template <typename E, int MF, int QT, int D, int R, int RS, int MODE, int METRIC, bool HAS_BIAS, int NW = 8>
+// KSL: the launch covers ONE K slice of D elements of rows that are wider (ScanArgs::ks_*): strided row and query addressing,
+// accumulators start from the partial sums of the slices before; MODE 3 (KSL only) stores the raw sums for the next slice.
+template <typename E, int MF, int QT, int D, int R, int RS, int MODE, int METRIC, bool HAS_BIAS, int NW = 8, bool KSL = false>
 __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* __restrict__ q16,
                                                        const float* __restrict__ aux0g, const float* __restrict__ qsq, const float* __restrict__ qscl,
                                                        int nq_end, BatchArgs f) {
@@ -210,8 +212,10 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
     static_assert(R % (MF * RS) == 0 && 8 % RS == 0 && R <= 64 && (R * CPR) % 256 == 0 && ROWB % 256 == 0 && PPL + NAUX <= 31, "tile geometry");
     static_assert(NW == 8 || (NW == 4 && MODE == 1 && RS == 1), "four waves: the filter pass only");
     static_assert(RS == 1 || RS == 2, "MODE 2 publishes 8 granules per query and workgroup: 4 lanes x 2 values, or 2 x 4 lanes x 1");
+    static_assert(MODE != 3 || (KSL && METRIC == 0 && !HAS_BIAS), "MODE 3 = raw partial sums of a K slice");
+    static_assert(!KSL || (MODE != 2 && NW == 8), "K slices run in the multi-kernel pipeline");
 
-    constexpr bool FILT = MODE != 0;            // the pass over all rows filters against per-query thresholds
+    constexpr bool FILT = MODE == 1 || MODE == 2;   // the pass over all rows filters against per-query thresholds
     constexpr bool ONE = MODE == 2;             // the whole call in this launch
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* auxbuf = reinterpret_cast<float*>(smem + 3 * STAGE);                    // [3 stages][2][64]
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
         q_ok[qt] = q < nq_end;
         ql[qt] = q - a.q0;
         const int qq = q_ok[qt] ? q : (nq_end - 1);
-        const uint4* src = reinterpret_cast<const uint4*>(q16 + (int64_t)qq * D) + h;
+        const uint4* src = reinterpret_cast<const uint4*>(KSL ? q16 + (int64_t)qq * a.ks_dfull + a.ks_off / ES : q16 + (int64_t)qq * D) + h;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             uint4 v = src[CPS * s];
@@ -379,14 +383,15 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
     auto issue_rows = [&](int64_t row0, int st) {
         const int64_t last = n_rows - 1 - row0;
         char* sdst = smem + st * STAGE;
-        const char* tile_base = Vb + row0 * (int64_t)ROWB;
+        const int64_t pitch = KSL ? a.ks_pitch : (int64_t)ROWB;
+        const char* tile_base = Vb + row0 * pitch + (KSL ? a.ks_off : 0);
 #pragma unroll
         for (int j = 0; j < PPL; ++j) {
             const int pc = (w & 3) + 4 * j;
             const int slot = pc * 64 + lane;
             const int r = slot / CPR, cpos = slot - r * CPR;
             const int rr = r <= (int)last ? r : (int)last;
-            const unsigned int off = (unsigned int)(rr * ROWB + (cpos ^ (r & 15)) * 16);
+            const unsigned int off = (unsigned int)(rr * (int)pitch + (cpos ^ (r & 15)) * 16);
             __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(tile_base + off), HDB_LDS_PTR(sdst + pc * 1024), 16, 0, 2);
         }
     };
@@ -676,6 +681,26 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
                 for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                     for (int e = 0; e < 4 * NGRP; ++e) acc[qt][rt][e] = 0.f;
+            if constexpr (KSL) {
+                if (a.ks_partial_in) {               // the sums of the K slices before this one (same layout as MODE 0's scores)
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                            for (int g = 0; g < NGRP; ++g) {
+                                const int rl0 = grp_row(rt, g);
+                                const float* src = a.ks_partial_in + (int64_t)(q_ok[qt] ? ql[qt] : 0) * a.ks_ld + (tA * R + rl0);
+                                if (q_ok[qt] && row0 + rl0 + 3 < n_rows) {
+                                    const float4 pv = *reinterpret_cast<const float4*>(src);
+                                    acc[qt][rt][4 * g] = pv.x; acc[qt][rt][4 * g + 1] = pv.y; acc[qt][rt][4 * g + 2] = pv.z; acc[qt][rt][4 * g + 3] = pv.w;
+                                } else if (q_ok[qt]) {
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) if (row0 + rl0 + j < n_rows) acc[qt][rt][4 * g + j] = src[j];
+                                }
+                            }
+                }
+            }
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 if (s + PF < KS) fetch(s + PF, abuf[(s + PF) % (PF + 1)]);
@@ -692,7 +717,7 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
             // bias: the raw dot (dot/||v||) against thr divided by the per-query multiplier.
             const float* ax0 = auxbuf + (st_cur * 2 + 0) * 64;
             const float* ax1 = auxbuf + (st_cur * 2 + 1) * 64;
-            if (METRIC != 0 || HAS_BIAS || MODE == 0) {
+            if (MODE != 3 && (METRIC != 0 || HAS_BIAS || MODE == 0)) {
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
@@ -725,7 +750,26 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
                     }
                 }
             }
-            if (MODE == 0) {
+            if constexpr (MODE == 3) {                   // raw partial sums for the next K slice
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                    for (int g = 0; g < NGRP; ++g) {
+                        const int rl0 = grp_row(rt, g);
+                        const int64_t rowg = row0 + rl0;
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt) {
+                            if (q_ok[qt]) {
+                                float* dst = a.ks_partial_out + (int64_t)ql[qt] * a.ks_ld + (tA * R + rl0);
+                                if (rowg + 3 < n_rows) *reinterpret_cast<float4*>(dst) = make_float4(acc[qt][rt][4 * g], acc[qt][rt][4 * g + 1], acc[qt][rt][4 * g + 2], acc[qt][rt][4 * g + 3]);
+                                else {
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) if (rowg + j < n_rows) dst[j] = acc[qt][rt][4 * g + j];
+                                }
+                            }
+                        }
+                    }
+            } else if (MODE == 0) {
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
 #pragma unroll
@@ -1039,6 +1083,34 @@ static int launch_one(const ScanArgs& a, const void* q16, const float* aux0, con
     if (f) fa = *f;
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a, (const E*)q16, aux0, qsq, qscl, a.q0 + nq_launch, fa);
     return (int)hipGetLastError();
+}
+
+// One K slice of a wide-row scan (hdb_mfma_ksplit.hip): mode 3 = raw partial sums out, 0 / 1 = the last slice with the metric's epilogue
+template <typename E, int D, int R, int MODE, int METRIC, bool HAS_BIAS>
+static int launch_kslice_one(const ScanArgs& a, const void* q16, const float* aux0, const float* qsq, const float* qscl, int nq_launch, int blocks, hipStream_t st) {
+    auto kern = hdb_mfma_kernel<E, 16, 1, D, R, 1, MODE, METRIC, HAS_BIAS, 8, true>;
+    const size_t lds = mfma_lds_bytes(R * D * (int)sizeof(E));
+    static unsigned long long attr_done = 0;
+    hipError_t e = hdb_lds_attr_once(reinterpret_cast<const void*>(kern), (int)lds, &attr_done);
+    if (e != hipSuccess) return (int)e;
+    const dim3 grid(blocks, (nq_launch + 8 * 16 - 1) / (8 * 16));
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a, (const E*)q16, aux0, qsq, qscl, a.q0 + nq_launch, BatchArgs());
+    return (int)hipGetLastError();
+}
+template <typename E, int D, int R>
+static int launch_kslice(const ScanArgs& a, int mode, const void* q16, const float* sqnorm, const float* qsq, const float* qscl, int nq_launch, int blocks, hipStream_t st) {
+    if (mode == 3) return launch_kslice_one<E, D, R, 3, 0, false>(a, q16, nullptr, qsq, qscl, nq_launch, blocks, st);
+    const bool b = a.bias != nullptr;
+#define HDB_KS_CASE(MODE_)                                                                                                                        \
+    if (a.metric == HDB_DOT) return b ? launch_kslice_one<E, D, R, MODE_, 0, true>(a, q16, nullptr, qsq, qscl, nq_launch, blocks, st)              \
+                                      : launch_kslice_one<E, D, R, MODE_, 0, false>(a, q16, nullptr, qsq, qscl, nq_launch, blocks, st);            \
+    if (a.metric == HDB_COSINE) return b ? launch_kslice_one<E, D, R, MODE_, 1, true>(a, q16, a.inv_norm, qsq, qscl, nq_launch, blocks, st)        \
+                                         : launch_kslice_one<E, D, R, MODE_, 1, false>(a, q16, a.inv_norm, qsq, qscl, nq_launch, blocks, st);      \
+    if (a.metric == HDB_EUCLIDEAN) return b ? launch_kslice_one<E, D, R, MODE_, 2, true>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st)         \
+                                            : launch_kslice_one<E, D, R, MODE_, 2, false>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
+    if (mode == 0) { HDB_KS_CASE(0) } else { HDB_KS_CASE(1) }
+#undef HDB_KS_CASE
+    return (int)hipErrorNotSupported;
 }
 
 // the four-wave measurement variant of the filter pass (dot product, no bias)

@@ -1774,3 +1774,55 @@ def test_bits_single_launch_equals_multi_kernel_and_exact(orc, dt, n, d):
         assert ix.stat("fused") == 3 and (int(st[2].item()) & Q_NAN) and not (int(st[0].item()) & Q_NAN)
     finally:
         ix.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# 14. wide rows on the matrix cores through K slices (hdb_mfma_ksplit.hip): float32 d = 1024 / 1536, fp16 d = 2048 / 3072 / 4096
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt,n,d,nq", [(np.float32, 40_017, 1536, 64), (np.float32, 30_000, 1024, 17), (np.float16, 50_003, 2048, 64),
+                                        (np.float16, 20_000, 3072, 130), (np.float16, 20_017, 4096, 33)])
+def test_wide_rows_k_slices_match_valu_scan_and_oracle(orc, dt, n, d, nq):
+    """Batches on rows too wide for one wave's query fragments ride the matrix cores in K slices (partial sums in a float32
+    buffer between the launches): same rows as the VALU scan (4 queries per pass) for dot / cosine / euclidean, with bias and
+    row mask, ragged last tile, an exact duplicate (euclidean: re-scored directly) -- and the oracle's float64 scores."""
+    import torch
+    from hyperdb._native import GpuIndex, METRIC_IDS
+    g = torch.Generator(device="cuda").manual_seed(n + d)
+    V = torch.randn((n, d), generator=g, device="cuda").to(torch.float16 if dt == np.float16 else torch.float32)
+    Q = torch.randn((nq, d), generator=g, device="cuda").to(V.dtype).float()       # (fp16 matrices multiply with fp16 copies of the queries)
+    Q[0] = V[n - 3].float()
+    ix = GpuIndex(V)
+    try:
+        bias = (torch.rand(n, generator=g, device="cuda") * 0.2).float()
+        mask = (torch.rand(n, generator=g, device="cuda") < 0.3).to(torch.uint8)
+        tol = 1e-3 if dt == np.float16 else 1e-5
+        Vh = V.cpu().numpy()
+        for metric in ("cosine_similarity", "dot_product", "euclidean_metric"):
+            mid = METRIC_IDS[metric]
+            for setup in ("plain", "mask+bias"):
+                ix.set_bias(bias if "bias" in setup else None)
+                ix.set_row_mask(mask if "mask" in setup else None)
+                ix.set_option("use_mfma", 1)
+                mi, ms, mst = ix.topk_device(Q, 50, mid)
+                assert ix.stat("mfma") == 1 and ix.stat("path") == 1 and ix.stat("fused") == 0 and int(mst.abs().sum().item()) == 0
+                ix.set_option("use_mfma", 0)
+                vi, vs, vst = ix.topk_device(Q, 50, mid)
+                assert ix.stat("mfma") == 0 and int(vst.abs().sum().item()) == 0
+                ix.set_option("use_mfma", 1)
+                mi_h, ms_h, vi_h, vs_h = mi.cpu().numpy(), ms.cpu().numpy(), vi.cpu().numpy(), vs.cpu().numpy()
+                for qi in range(nq):
+                    assert orc.same_result_modulo_ties(mi_h[qi], ms_h[qi], vi_h[qi], vs_h[qi], 5e-5 if dt == np.float16 else 1e-5), (metric, setup, qi)
+                if setup == "plain":
+                    for qi in (0, 1, nq - 1):
+                        orc.check_topk(mi_h[qi], ms_h[qi], Vh, Q[qi].cpu().numpy(), metric, 50, tol=tol)
+                    if metric == "euclidean_metric":
+                        assert mi_h[0][0] == n - 3 and abs(ms_h[0][0] - 1.0) < 1e-6
+            ix.set_bias(None); ix.set_row_mask(None)
+            ei, es, _ = ix.topk_device(Q[:8], 50, mid, exact=True)       # the exact selection through the K-slice score writer
+            assert ix.stat("mfma") == 1 and ix.stat("path") == 2
+            fi, fs, _ = ix.topk_device(Q[:8], 50, mid)
+            if metric != "euclidean_metric":
+                assert torch.equal(ei, fi) and torch.equal(es, fs)
+        ix.topk_device(Q[:3], 10, METRIC_IDS["dot_product"]); assert ix.stat("mfma") == 0      # up to 4 queries: one VALU pass
+    finally:
+        ix.close()

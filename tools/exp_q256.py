@@ -42,7 +42,7 @@ print(json.dumps({"parity_ok": bool(ok), "kernel_us": times}), flush=True)
 def build(variants):
     os.makedirs(OUT, exist_ok=True)
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    objs = [os.path.join(CSRC, 'obj', f'{n}.o') for n in ('hdb_mfma', 'hdb_mfma_f32', 'hdb_mfma_f32b', 'hdb_mfma_qt2', 'hdb_mfma_wide', 'hdb_mfma_mid', 'hdb_mfma_narrow', 'hdb_mfma_1k', 'hdb_mfma_fused', 'hdb_mfma_fused_wide', 'hdb_scan', 'hdb_select', 'hdb_sort', 'hdb_rows', 'hdb_api')]
+    objs = [os.path.join(CSRC, 'obj', f) for f in sorted(os.listdir(os.path.join(CSRC, 'obj'))) if f.endswith('.o') and f != 'hdb_mfma_d384.o']
     procs = []
     for v in variants:
         o = os.path.join(OUT, f'mfma_{v}.o')

@@ -8,7 +8,7 @@ OUT = os.path.join(ROOT, 'local-hyperdb_amd', 'lib', 'stamps')
 def build():
     os.makedirs(OUT, exist_ok=True)
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    objs = [os.path.join(CSRC, 'obj', f'{n}.o') for n in ('hdb_mfma', 'hdb_mfma_d384', 'hdb_mfma_f32', 'hdb_mfma_f32b', 'hdb_mfma_qt2', 'hdb_mfma_wide', 'hdb_mfma_mid', 'hdb_mfma_narrow', 'hdb_mfma_1k', 'hdb_mfma_fused_wide', 'hdb_scan', 'hdb_select', 'hdb_sort', 'hdb_rows', 'hdb_api')]
+    objs = [os.path.join(CSRC, 'obj', f) for f in sorted(os.listdir(os.path.join(CSRC, 'obj'))) if f.endswith('.o') and f != 'hdb_mfma_fused.o']
     o = os.path.join(OUT, 'fused.o')
     subprocess.check_call([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-pass-failed', '-DHDB_FUSED_STAMPS=1',
                            '-c', os.path.join(CSRC, 'hdb_mfma_fused.hip'), '-o', o])
