@@ -52,6 +52,8 @@ int hdb_launch_mfma_scan(const ScanArgs* args, int dtype, int mode, int nq_launc
                          const float* qsq, const float* qscl, int max_blocks, int variant, void* stream, const BatchArgs* f);
 int hdb_mfma_batch_capacity(int dtype, int d);
 int hdb_mfma_ksplit_slices(int dtype, int d);
+int hdb_l1_tile_supported(int dtype, int d);
+int hdb_launch_l1_tile(const ScanArgs* args, int dtype, int mode, int nq_launch, int max_blocks, void* stream);
 int hdb_bits_fused_supported(int metric, int nq, int W, uint32_t kk);
 int hdb_launch_bits_fused(const BitsArgs* args, int jaccard, int max_blocks, void* stream);
 size_t hdb_mfma_batch_ctl_bytes(int wgs);
@@ -135,6 +137,7 @@ struct hdb_index {
     int64_t dyn_heavy = 0;            // ... also when all eight waves multiply (measured: 1.3-5 % slower at 256 queries, profiles/r3_q256_clock.json)
     int64_t host_poll = 1;            // hdb_topk_host + single-launch pipeline + pinned record: poll the status words instead of the stream
     int64_t use_fused = 1;            // 1-4 dot / cosine queries on an fp16 matrix: the whole call in ONE kernel (hdb_mfma_fused.h)
+    int64_t use_l1_tile = 1;          // manhattan: dense passes through the LDS-staged tile kernel (hdb_l1_tile.hip)
     int64_t use_batch1 = 1;           // 5+ queries (euclidean: 1+) on the matrix cores, k <= 128: the whole call in ONE launch per <= 256 queries (needs use_fused)
     int64_t fused_timeout_us = 2000;  // bound of every in-kernel spin of those kernels
     int64_t finalize_threads = 1024;  // workgroup size of hdb_finalize_kernel (256 | 512 | 1024)
@@ -343,6 +346,7 @@ extern "C" int hdb_set_option(hdb_index* ix, const char* name, int64_t value) {
     else if (!strcmp(name, "host_direct")) ix->host_direct = value;
     else if (!strcmp(name, "use_fused")) ix->use_fused = value;
     else if (!strcmp(name, "use_batch1")) ix->use_batch1 = value;
+    else if (!strcmp(name, "use_l1_tile")) ix->use_l1_tile = value;
     else if (!strcmp(name, "host_poll")) ix->host_poll = value;
     else if (!strcmp(name, "dyn_tiles")) ix->dyn_tiles = value;
     else if (!strcmp(name, "dyn_min_mb")) ix->dyn_min_mb = std::max<int64_t>(0, value);
@@ -444,6 +448,10 @@ static int run_scan(hdb_index* ix, ScanArgs& a, int mode, int cq, const QueryBuf
     a.qinv = qb.qinv;
     if (is_bits_metric(a.metric)) {
         LAUNCH_TRY(hdb_launch_hamming(&a, mode, cq, ix->bits, ix->bits_npad, ix->W, qb.qbits, st));
+    } else if (a.metric == HDB_MANHATTAN && ix->use_l1_tile && cq >= 2 && a.tile_stride == 1 && !a.mask && !a.raw && a.n > HDB_CAND_CAP &&
+               hdb_l1_tile_supported(ix->dtype, ix->d)) {
+        // dense manhattan passes: tiles staged once in LDS, queries in registers, 8-16 queries per pass (hdb_l1_tile.hip)
+        LAUNCH_TRY(hdb_launch_l1_tile(&a, ix->dtype, mode, cq, (int)ix->max_blocks, st));
     } else if (mfma) {
         LAUNCH_TRY(hdb_launch_mfma_scan(&a, ix->dtype, mode, cq, qb.q16, ix->sqnorm, qb.qsq, qb.qscl, (int)ix->max_blocks, (int)ix->mfma_variant, st, nullptr));
     } else {
@@ -653,7 +661,8 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     // the MFMA scan has no mask input: excluded rows get a bias of -inf instead (never appended, like the VALU scan)
     const float* bias_eff = ix->bias;
     const uint8_t* mask_eff = ix->mask;
-    if ((mfma || fused) && ix->mask) {
+    const bool l1tile = metric == HDB_MANHATTAN && ix->use_l1_tile && !small && hdb_l1_tile_supported(ix->dtype, ix->d);
+    if ((mfma || fused || l1tile) && ix->mask) {
         if (n > ix->mbias_rows) {
             if (ix->mbias) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(ix->mbias)); ix->mbias = nullptr; }
             const int64_t rows = n + n / 4 + 64;

@@ -263,8 +263,8 @@ class HyperDB:
 
     @staticmethod
     def _hashable_key(query_input, top_k, return_similarities, filters, recency_bias, timestamp_key, metric, ann_percent):
-        if isinstance(query_input, np.ndarray):
-            query_input = tuple(query_input.ravel().tolist()) + (query_input.shape,)
+        if isinstance(query_input, np.ndarray):               # the array's bytes (1 us) instead of a tuple of its values (8 us at d=384)
+            query_input = (query_input.tobytes(), query_input.dtype.str, query_input.shape)
         elif isinstance(query_input, list):
             query_input = tuple(np.asarray(query_input).ravel().tolist())
         return (query_input, top_k, return_similarities, HyperDB._filter_key(filters), recency_bias, timestamp_key, metric, ann_percent)
@@ -588,15 +588,16 @@ class HyperDB:
         if n_avail == 1:
             print("Info: Only one document left.")                               # ranking_algorithm.py:189-191
         out = []
+        documents, sources = self.documents, self.source_indices
         for qi in range(len(Q)):
             rows = idx[qi][idx[qi] >= 0]
-            docs = self._docs_of_rows(rows)
-            # one row left: the reference's scores come back 2-D (:191), so scores[i] is a 1-element array
-            val = (lambda s_: np.array([float(s_)])) if n_avail == 1 else float
-            if return_similarities:
-                out.append([(self.documents[r], val(sc[qi][j]), self.source_indices[r]) for j, r in enumerate(docs)])
+            docs = self._docs_of_rows(rows).tolist()
+            if not return_similarities:
+                out.append([documents[r] for r in docs])
+            elif n_avail == 1:                                    # one row left: the reference's scores come back 2-D (:191)
+                out.append([(documents[r], np.array([float(sc[qi][j])]), sources[r]) for j, r in enumerate(docs)])
             else:
-                out.append([self.documents[r] for r in docs])
+                out.append([(documents[r], s_, sources[r]) for r, s_ in zip(docs, sc[qi].tolist())])
         return out
 
     def query(self, query_input, top_k=5, return_similarities=True, filters=None, recency_bias=0, timestamp_key=None,

@@ -8,11 +8,12 @@ so the only exchange step is the gather of each shard's k best (SURVEY.md sectio
     torch.distributed.all_gather_into_tensor (backend "nccl" == RCCL over xGMI; payload = nq*k*12 B per rank)
     hdb_merge_topk_packed on every rank   ->  identical global top-k everywhere
 
-On ONE node (the launch model of bench.py: one process per GPU of a node) records of up to 64 KiB per rank do not take
-the collective: every rank's hdb_topk_host leaves its record in host memory anyway (the answer is for the host), so the
-ranks swap records through a shared-memory segment (HostExchange: sequence-tagged slots, two parities) and merge with
-hdb_merge_topk_host -- ~5 us instead of a collective + a merge launch + another stream synchronisation (>= 30 us at 1.2 KB).
-Larger batches, several nodes, or HDB_EXCHANGE=collective keep the all-gather.
+That all-gather is the default exchange.  On ONE node (the launch model of bench.py: one process per GPU of a node) there is a
+second transport for records of up to 64 KiB per rank, chosen with exchange="host" / HDB_EXCHANGE=host (or "auto"): every
+rank's hdb_topk_host leaves its record in host memory anyway (the answer is for the host), so the ranks swap records through a
+shared-memory segment (HostExchange: sequence-tagged slots, two parities) and merge with hdb_merge_topk_host -- ~5 us on the
+build container against a collective + a merge launch + another stream synchronisation (>= 30 us at 1.2 KB on one GPU).  No
+multi-GPU run has compared the two yet: bench.py times both in the same run and uses the faster one for `value`.
 
 Ordering is the build's total order (score descending, global row ascending), so the result does not
 depend on the number of shards.  Queries whose sampled threshold failed on ANY shard (status != 0 in
@@ -230,7 +231,10 @@ class ShardedIndex:
         self.n_total = n_total
         self.force_exchange = force_exchange and group is not None     # run gather+merge even with one rank (tests)
         self._hx = None
-        mode = exchange or os.environ.get("HDB_EXCHANGE") or "auto"
+        # default: the RCCL all-gather (what the north star names).  The shared-memory swap is chosen explicitly -- exchange="host" /
+        # HDB_EXCHANGE=host -- or by a caller that has timed both on its node (bench.py calibrates and reports both); "auto" =
+        # the swap wherever every rank sits on one node.
+        mode = exchange or os.environ.get("HDB_EXCHANGE") or "collective"
         if mode not in ("host", "collective", "auto"):
             raise ValueError("exchange must be 'host', 'collective' or None")
         if self.world > 1 and mode != "collective" and hasattr(self.engine, "topk_record_host"):
@@ -263,25 +267,58 @@ class ShardedIndex:
             self._hx = None
 
     # -- helpers -------------------------------------------------------------------------------
+    POISON = 1 << 30          # status bit of a record published in place of a shard's answer: that rank's local top-k raised
+
+    @staticmethod
+    def _poison_record(nb, nq, k):
+        rec = np.zeros(nb, dtype=np.uint8)
+        rec[:nq * k * 8].view(np.int64)[:] = -1
+        rec[nq * k * 8:nq * k * 12].view(np.float32)[:] = -np.inf
+        rec[nq * k * 12:nq * k * 12 + nq * 4].view(np.int32)[:] = ShardedIndex.POISON
+        return rec
+
     def _gather_merge(self, Q, k, metric_id, exact):
-        """-> host views (idx, score, status) of the merged global result."""
+        """-> host views (idx, score, status) of the merged global result.
+
+        A rank whose local top-k raises still takes part in the exchange, with a poison record (status bit 30 on every
+        query): its peers would otherwise wait for it until the timeout, and the sequence counters of the shared-memory
+        swap (or the collective) would differ between the ranks for good.  The failing rank re-raises its own error, the
+        others raise a RuntimeError when they see the bit."""
         eng = self.engine
         nq = int(Q.shape[0])
         nb = eng.packed_bytes(nq, k)
+        err = None
         if self._hx is not None and nb <= self._hx.slot_bytes:
-            mine = eng.topk_record_host(Q, k, metric_id, exact=exact)
-            return self._hx.exchange_merge(mine, nq, k)
-        rec = eng.new_record(nb, 0)
-        eng.topk_packed(Q, k, metric_id, rec, exact=exact)
-        if self.world == 1 and not self.force_exchange:
-            return eng.record_to_host(rec, nq, k)               # already the global answer
-        gathered = eng.new_record(nb * self.world, 1)
-        dist.all_gather_into_tensor(gathered, rec, group=self.group)
-        if hasattr(eng, "merge_packed_to_host"):
-            return eng.merge_packed_to_host(gathered, self.world, nq, k)
-        merged = eng.new_record(nb, 2)
-        eng.merge_packed_into(gathered, self.world, nq, k, merged)
-        return eng.record_to_host(merged, nq, k)
+            try:
+                mine = eng.topk_record_host(Q, k, metric_id, exact=exact)
+            except Exception as e:                               # noqa: BLE001 -- re-raised below, after the exchange
+                err, mine = e, self._poison_record(nb, nq, k)
+            out = self._hx.exchange_merge(mine, nq, k)
+        else:
+            rec = eng.new_record(nb, 0)
+            try:
+                eng.topk_packed(Q, k, metric_id, rec, exact=exact)
+            except Exception as e:                               # noqa: BLE001
+                err = e
+                if self.world > 1 or self.force_exchange:
+                    rec.copy_(torch.from_numpy(self._poison_record(nb, nq, k)))
+            if self.world == 1 and not self.force_exchange:
+                if err is not None:
+                    raise err
+                return eng.record_to_host(rec, nq, k)           # already the global answer
+            gathered = eng.new_record(nb * self.world, 1)
+            dist.all_gather_into_tensor(gathered, rec, group=self.group)
+            if hasattr(eng, "merge_packed_to_host"):
+                out = eng.merge_packed_to_host(gathered, self.world, nq, k)
+            else:
+                merged = eng.new_record(nb, 2)
+                eng.merge_packed_into(gathered, self.world, nq, k, merged)
+                out = eng.record_to_host(merged, nq, k)
+        if err is not None:
+            raise err
+        if (out[2] & self.POISON).any():
+            raise RuntimeError("another rank failed while computing its shard's top-k (see that rank's error)")
+        return out
 
     # -- public --------------------------------------------------------------------------------
     def set_recency(self, timestamps, recency_bias):

@@ -1826,3 +1826,54 @@ def test_wide_rows_k_slices_match_valu_scan_and_oracle(orc, dt, n, d, nq):
         ix.topk_device(Q[:3], 10, METRIC_IDS["dot_product"]); assert ix.stat("mfma") == 0      # up to 4 queries: one VALU pass
     finally:
         ix.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# 15. manhattan batches through the LDS-staged tile kernel (hdb_l1_tile.hip)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt,n,d", [(np.float16, 120_003, 384), (np.float16, 60_000, 256), (np.float16, 40_017, 128),
+                                     (np.float32, 70_001, 384), (np.float32, 50_000, 128)])
+def test_manhattan_tile_kernel_matches_scan_and_oracle(orc, dt, n, d):
+    """manhattan_distance for 1-20 queries per call: one pass over V with the queries in registers against the 4-query VALU
+    scan (same rows; fp16 data subtracts in fp16 like the reference, so scores agree to fp16 rounding of the differences) and the
+    oracle's float64 scores; bias, row mask, ragged last tile, an exact duplicate (distance 0 -> similarity exactly 1)."""
+    import torch
+    from hyperdb._native import GpuIndex, METRIC_IDS
+    g = torch.Generator(device="cuda").manual_seed(n + d)
+    V = torch.randn((n, d), generator=g, device="cuda").to(torch.float16 if dt == np.float16 else torch.float32)
+    Q = torch.randn((20, d), generator=g, device="cuda").to(V.dtype).float()
+    Q[0] = V[n - 2].float()
+    ix = GpuIndex(V)
+    try:
+        mid = METRIC_IDS["manhattan_distance"]
+        bias = (torch.rand(n, generator=g, device="cuda") * 0.01).float()
+        mask = (torch.rand(n, generator=g, device="cuda") < 0.3).to(torch.uint8)
+        Vh = V.cpu().numpy()
+        rel = 2e-4 if dt == np.float16 else 1e-6
+        for setup in ("plain", "bias", "mask+bias"):
+            ix.set_bias(bias if "bias" in setup else None)
+            ix.set_row_mask(mask if "mask" in setup else None)
+            for nq, k in ((1, 100), (5, 10), (8, 128), (20, 50)):
+                ix.set_option("use_l1_tile", 1)
+                ti, ts, tst = ix.topk_device(Q[:nq], k, mid)
+                ix.set_option("use_l1_tile", 0)
+                si, ss, sst = ix.topk_device(Q[:nq], k, mid)
+                ix.set_option("use_l1_tile", 1)
+                assert int(tst.abs().sum().item()) == 0 and int(sst.abs().sum().item()) == 0
+                ti_h, ts_h, si_h, ss_h = ti.cpu().numpy(), ts.cpu().numpy(), si.cpu().numpy(), ss.cpu().numpy()
+                for qi in range(nq):
+                    a_, b_ = np.sort(ts_h[qi])[::-1], np.sort(ss_h[qi])[::-1]
+                    assert np.all(np.abs(a_ - b_) <= rel * np.maximum(np.abs(b_), 1e-6)), (setup, nq, k, qi)
+                    common = len(set(ti_h[qi].tolist()) & set(si_h[qi].tolist()))
+                    assert common >= k - max(1, k // 20), (setup, nq, k, qi, common)          # near-ties at the k-th place may swap
+            if setup == "plain":
+                idx, sc = ix.topk(Q[:3], 100, mid)
+                for qi in range(3):
+                    orc.check_topk(idx[qi], sc[qi], Vh, Q[qi].cpu().numpy(), "manhattan_distance", 100, tol=1e-3 if dt == np.float16 else 1e-5)
+                assert idx[0][0] == n - 2 and sc[0][0] == 1.0
+        ix.set_bias(None); ix.set_row_mask(None)
+        ei, es, _ = ix.topk_device(Q[:6], 50, mid, exact=True)            # exact selection through the tile kernel's score writer
+        fi, fs, _ = ix.topk_device(Q[:6], 50, mid)
+        assert torch.equal(ei, fi) and torch.equal(es, fs)
+    finally:
+        ix.close()

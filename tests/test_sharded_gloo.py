@@ -248,3 +248,54 @@ def test_host_exchange_times_out_when_a_rank_does_not_publish(tmp_path):
     r1 = open(tmp_path / "rank1.txt").read().split("|")
     assert r0[0] == "1" and r1[0] == "1"
     assert "did not publish" in r0[1] and r1[1] == ""
+
+
+def _poison_worker(rank, world, port, out_dir, exchange):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "local-hyperdb_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hyperdb.sharded import ShardedIndex, shard_bounds
+        rng = np.random.default_rng(5)
+        n, d, k = 600, 16, 7
+        V = rng.standard_normal((n, d)).astype(np.float32)
+        Q = torch.from_numpy(rng.standard_normal((3, d)).astype(np.float32))
+        lo, hi = shard_bounds(n, world, granule=16)[rank]
+
+        class Flaky(OracleEngine):
+            boom = False
+
+            def topk_packed(self, Q_, k_, metric_id, record, exact=False):
+                if self.boom:
+                    raise ValueError("shard exploded")
+                return super().topk_packed(Q_, k_, metric_id, record, exact=exact)
+        eng = Flaky(V[lo:hi], lo)
+        sh = ShardedIndex(None, n_total=n, group=dist.group.WORLD, engine=eng, exchange=exchange)
+        good, _ = sh.query(Q, k, 1)
+        eng.boom = rank == 1                                 # the next call fails on rank 1 only
+        seen = ""
+        try:
+            sh.query(Q, k, 1)
+        except Exception as e:                               # noqa: BLE001
+            seen = type(e).__name__ + ":" + str(e)
+        eng.boom = False
+        again, _ = sh.query(Q, k, 1)                         # counters stayed aligned: the next exchange works
+        with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+            f.write(f"{seen}|{int(np.array_equal(good, again))}")
+        sh.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange", ["collective", "host"])
+def test_a_failing_rank_poisons_the_exchange_instead_of_hanging_it(tmp_path, exchange):
+    """a rank that raises before publishing left its peers spinning until the timeout and the sequence counters
+    apart for good.  It now publishes a poison record: every rank raises at once, and the next query works."""
+    port = 37500 + (os.getpid() % 2000) + (10 if exchange == "host" else 0)
+    mp.spawn(_poison_worker, args=(2, port, str(tmp_path), exchange), nprocs=2, join=True)
+    r0 = open(tmp_path / "rank0.txt").read().split("|")
+    r1 = open(tmp_path / "rank1.txt").read().split("|")
+    assert r1[0] == "ValueError:shard exploded" and r0[0].startswith("RuntimeError:another rank failed")
+    assert r0[1] == "1" and r1[1] == "1"
