@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--n", type=int, default=10_000_000)
+    ap.add_argument("--n", "--rows", dest="n", type=int, default=10_000_000)      # (--rows: torch.distributed.run takes a bare --n for its own options)
     ap.add_argument("--d", type=int, default=384)
     ap.add_argument("--k", type=int, default=100)
     ap.add_argument("--dtype", default="fp16", choices=["fp16", "fp32"])

@@ -46,7 +46,9 @@ def stats(src, dst):
 
 def pmc(fetch_dir, write_dir, needle, dst):
     def avg(d, counter):
-        vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(find(d, "_counter_collection.csv")))
+        vals = [float(r["Counter_Value"])
+                for path in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)   # one file per process
+                for r in csv.DictReader(open(path))
                 if needle in r["Kernel_Name"] and r["Counter_Name"] == counter]
         return (sum(vals) / len(vals), len(vals)) if vals else (0.0, 0)
     f, nf = avg(fetch_dir, "FETCH_SIZE")

@@ -34,6 +34,10 @@ for pass in a b; do
 done
 echo "=== q256 clock (shipped single launch, knock-outs, five-kernel filter pass, four-wave variant)"
 timeout -k 10 900 python tools/clock_q256.py run $O/r3_q256_clock.json > $O/clock_r3.log 2>&1; rc=$?; tail -3 $O/clock_r3.log | cut -c1-300; guard $rc
+echo "=== rehearsal of the 2-rank control flow on one GPU (timings meaningless)"
+HDB_BENCH_REHEARSAL=1 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 20 --warmup 5 --rows 2000000 --batch-q 64 --batch-steps 3 > $O/bench_r3_rehearsal.log 2>&1; rc=$?; tail -1 $O/bench_r3_rehearsal.log | cut -c1-900; guard $rc
+echo "=== api / call overhead"
+timeout -k 10 300 python tools/time_call_overhead.py > $O/overhead_r3.log 2>&1; grep -v amdgpu $O/overhead_r3.log | tail -12
 echo "=== bench"
 timeout -k 10 600 python bench.py --steps 200 --warmup 10 --extra c2,c5,hamming > $O/bench_r3.log 2>&1; rc=$?; tail -1 $O/bench_r3.log | cut -c1-600; guard $rc
 exit 0
