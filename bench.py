@@ -385,8 +385,23 @@ def main():
             t0 = time.perf_counter()
             db.query(qs[i], top_k=args.k, metric=args.metric)
             t_query[i] = time.perf_counter() - t0
+        # the same with both recency decays (hyperdb.py:1310-1346, :1555): the timestamps of the key are what the facade would
+        # extract from the documents once (30 days, seeded); first call = column upload + decay kernel, later calls = cached bias
+        db.metadata_keys = ["timestamp"]
+        db._ts_cache["timestamp"] = 1.7e9 + np.random.default_rng(7).random(hi - lo) * 30 * 86400.0
+        t0 = time.perf_counter()
+        db.query(qs[0] + 2e-3, top_k=args.k, metric=args.metric, recency_bias=0.5, timestamp_key="timestamp")
+        t_first = time.perf_counter() - t0
+        t_rec = np.empty(steps_api)
+        for i in range(steps_api):
+            t0 = time.perf_counter()
+            db.query(qs[i], top_k=args.k, metric=args.metric, recency_bias=0.5, timestamp_key="timestamp")
+            t_rec[i] = time.perf_counter() - t0
+        host_passes = db.host_row_passes
         db._index = None
         api = {"sort_p50_ms": 1e3 * float(np.median(t_sort)), "query_p50_ms": 1e3 * float(np.median(t_query)),
+               "query_recency_p50_ms": 1e3 * float(np.median(t_rec)), "query_recency_first_call_ms": 1e3 * t_first,
+               "query_recency_host_row_passes": host_passes,
                "kernel_path_p50_ms": 1e3 * float(np.median(lat)), "queries": "numpy float32 on the host",
                "entry_points": "hyperdb.ranking_algorithm.hyperDB_ranking_algorithm_sort(handle, q, top_k) / HyperDB.query(q, top_k)"}
 

@@ -419,10 +419,10 @@ static int ensure_pscale(hdb_index* ix, hipStream_t st) {
 static int ensure_bits(hdb_index* ix, hipStream_t st) {
     if (ix->bits_valid) return HDB_OK;
     const int W = (ix->d + 31) / 32;
-    const int64_t npad = align_up((size_t)std::max<int64_t>(ix->n, 4), 4);
+    const int64_t npad = align_up((size_t)std::max<int64_t>(ix->n, 4), 256);      // whole 256-row blocks (hdb_bits_word)
     if (!ix->bits || ix->bits_npad < npad || ix->W != W) {
         if (ix->bits) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(ix->bits)); ix->bits = nullptr; }
-        const int64_t cap = align_up((size_t)(npad + npad / 4), 4);
+        const int64_t cap = align_up((size_t)(npad + npad / 4), 256);
         HIP_TRY(hipMalloc((void**)&ix->bits, (size_t)cap * W * sizeof(uint32_t)));
         ix->bits_npad = cap; ix->W = W;
     }

@@ -5,7 +5,8 @@
 // ~45 us of fixed cost around a ~70 us scan of the 480 MB of sign bits at N = 10M, d = 384).
 //
 // One persistent workgroup of 1024 threads per CU (16 waves: every thread keeps W 16-byte loads in flight); the scan itself is
-// hdb_hamming_kernel's: word-major sign bits, a thread owns four consecutive rows and all QH queries of the call.
+// hdb_hamming_kernel's: sign bits in 256-row blocks, word-major inside (hdb_bits_word), a thread owns four consecutive rows and
+// all QH queries of the call; a wave step (64 quads) reads one contiguous block of W KiB.
 //   prologue  every workgroup packs the sign bits of the queries (x > 0, hdb_qsign_kernel) into LDS and notes a NaN;
 //   sample    the strided, jittered row sample of the multi-kernel pipeline, split over the grid; every thread keeps the two
 //             largest scores it has seen per query; the workgroup reduces them to its eight largest per query (DPP wave
@@ -13,7 +14,8 @@
 //   exchange  the owner of query q (workgroup q) sweeps that query's G x 8 granules until all carry this call's epoch, takes
 //             the 8-th largest -- a lower bound of the 8-th largest sample score, which is all a threshold needs -- and
 //             publishes it as one {epoch, key} word; every workgroup polls the nq words;
-//   filter    the pass over all sign bits; rows at or above the threshold go to the per-query candidate lists;
+//   filter    the pass over all sign bits, handed out in two levels (1024-quad chunks from a global counter, 64-quad pieces from
+//             an LDS word) and begun before the threshold is there; rows at or above it go to the per-query candidate lists;
 //   finish    drain, agent-scope release, arrive; when every workgroup has arrived, the owner of each query sorts its list
 //             (hdb_finalize_body) and writes the k results and the status word; the last workgroup out zeroes the counters.
 // Scores are small integers (hamming) with massive ties: everything at the threshold's own level survives, the sample plan aims
@@ -42,7 +44,12 @@ extern "C" int hdb_debug_read_bits_stamps(unsigned long long* host_out, int wgs)
 typedef unsigned int u32x4b __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) unsigned long long hdb_bgu64;
 
+#ifndef HDB_BITS_THREADS
 #define HDB_BITS_THREADS 1024
+#endif
+#ifndef HDB_BITS_TAIL
+#define HDB_BITS_TAIL 0                  // 1: the last ~15 % of the pass is handed out in quarter chunks
+#endif
 #define HDB_BITS_WAVES (HDB_BITS_THREADS / 64)
 #define HDB_BITS_MAXW 512
 
@@ -60,7 +67,7 @@ __device__ __forceinline__ uint32_t hdb_wg_top8(uint32_t a, uint32_t b, uint32_t
     __syncthreads();
     uint32_t out = 0u;
     if (w == 0) {
-        uint32_t x = scratch[lane], y = scratch[64 + lane];          // 16 waves x 8 = 128 keys
+        uint32_t x = scratch[lane], y = HDB_BITS_WAVES > 8 ? scratch[64 + lane] : 0u;          // waves x 8 keys
         uint32_t hi = max(x, y), lo = min(x, y);
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
@@ -76,7 +83,7 @@ __device__ __forceinline__ uint32_t hdb_wg_top8(uint32_t a, uint32_t b, uint32_t
 
 template <bool JACCARD, int QH>
 __global__ __launch_bounds__(HDB_BITS_THREADS) void hdb_bits_fused_kernel(BitsArgs a) {
-    static_assert(HDB_BITS_WAVES == 16, "hdb_wg_top8 reads 128 keys");
+    static_assert(HDB_BITS_WAVES == 16 || HDB_BITS_WAVES == 8, "hdb_wg_top8 reads 64 or 128 keys");
     extern __shared__ __attribute__((aligned(16))) unsigned long long fbuf[];       // hdb_finalize_body's buffers first ...
     char* xbase = reinterpret_cast<char*>(fbuf) + (size_t)HDB_CAND_CAP * 16 + 2048 * 4 + 64;
     uint32_t* qb = reinterpret_cast<uint32_t*>(xbase);                                // ... then [QH][HDB_BITS_MAXW] query sign bits,
@@ -95,7 +102,7 @@ __global__ __launch_bounds__(HDB_BITS_THREADS) void hdb_bits_fused_kernel(BitsAr
 
     HDB_XSTAMP(0);
     // ---- prologue: sign bits of the queries (hdb_qsign_kernel), NaN flags
-    if (tid < 10) xflag[tid] = 0u;
+    if (tid < 10) xflag[tid] = tid == 8 ? (uint32_t)b << 6 : 0u;          // [8]: the first chunk of the filter pass is this workgroup's own
     for (int i = tid; i < QH * HDB_BITS_MAXW; i += HDB_BITS_THREADS) qb[i] = 0u;
     __syncthreads();
     {
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(HDB_BITS_THREADS) void hdb_bits_fused_kernel(BitsAr
             uint4 v[CW];
 #pragma unroll
             for (int c = 0; c < CW; ++c)
-                v[c] = (w0 + c < W) ? *reinterpret_cast<const uint4*>(a.bits + (int64_t)(w0 + c) * a.npad + 4 * i) : make_uint4(0, 0, 0, 0);
+                v[c] = (w0 + c < W) ? *hdb_bits_quad(a.bits, i, w0 + c, W) : make_uint4(0, 0, 0, 0);
 #pragma unroll
             for (int c = 0; c < CW; ++c) {
                 const uint32_t vv[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
@@ -243,6 +250,59 @@ __global__ __launch_bounds__(HDB_BITS_THREADS) void hdb_bits_fused_kernel(BitsAr
         }
         __syncthreads();
     }
+    // ---- filter, first step: every wave draws its first piece of the pass and scores it BEFORE it looks for the threshold (the
+    // exchange takes ~5 us; the scores wait in registers), owners after they have published theirs.
+    // Hand-out in two levels: a chunk = 1024 quads (16 pieces of 64 quads = one wave step of 12 KiB at d = 384) comes from the global
+    // counter, one returning atomic per chunk and workgroup, asked for while the chunk before is being worked on; the waves of the
+    // workgroup draw pieces from an LDS word {chunk << 6 | draws: up to 32 per chunk, 16 of them pieces}: no barrier, and a wave that the memory system serves late
+    // simply draws fewer pieces (static thread-interleaved split: wave 0 of the median workgroup was done 33 us before its last
+    // wave, workgroups differed by 19 us, profiles/r3_bits_timeline.txt).
+    uint32_t* const cq = xflag + 8;                              // [0] {chunk << 6 | draws}, [1] prefetched chunk + 1
+    constexpr uint32_t ENDC = 0x03FFFFFFu;
+    constexpr uint32_t NPC = HDB_BITS_WAVES, TP = NPC / 4;          // pieces per chunk, per quarter chunk of the tail
+    const uint32_t npieces = (uint32_t)((a.ntiles * 4 + 63) / 64);
+    uint32_t nbig = (npieces + NPC - 1) / NPC, nsmall = 0u;
+    if (HDB_BITS_TAIL && nbig >= 4u * (uint32_t)G) {
+        nbig = (uint32_t)((uint64_t)npieces * 85 / 100 / NPC);
+        nsmall = (npieces - nbig * NPC + TP - 1) / TP;
+    }
+    const uint32_t nchunks = nbig + nsmall;
+    auto draw = [&]() __attribute__((always_inline)) -> int64_t {        // wave-uniform: first quad of the piece, or -1 at the end
+        for (;;) {
+            uint32_t t = 0u;
+            if (lane == 0) t = __hip_atomic_fetch_add(&cq[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+            const uint32_t sub = t & 63u, chunk = t >> 6;
+            if (chunk == ENDC) return -1;
+            const uint32_t np = chunk < nbig ? NPC : TP;
+            const int64_t p0 = chunk < nbig ? (int64_t)chunk * NPC : (int64_t)nbig * NPC + (int64_t)(chunk - nbig) * TP;
+            if (sub == 1u && lane == 0) {                                  // ask for the chunk after this one
+                const uint32_t nx = (uint32_t)G + __hip_atomic_fetch_add(a.ctl + HDB_BATCH_CTL_TILE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&cq[1], nx + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            if (sub < np) return (p0 + sub) * 64;
+            if (sub == np) {                                               // this wave swaps the next chunk in and takes its piece 0
+                uint32_t nx = 0u;
+                if (lane == 0) {
+                    while ((nx = __hip_atomic_load(&cq[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0u) __builtin_amdgcn_s_sleep(1);
+                    __hip_atomic_store(&cq[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(&cq[0], nx - 1u >= nchunks ? ENDC << 6 : (((nx - 1u) << 6) | 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                nx = (uint32_t)__builtin_amdgcn_readfirstlane((int)nx) - 1u;
+                if (nx >= nchunks) return -1;
+                return (nx < nbig ? (int64_t)nx * NPC : (int64_t)nbig * NPC + (int64_t)(nx - nbig) * TP) * 64;
+            }
+            if (lane == 0)                                                 // pieces all taken: wait for the swap
+                while ((__hip_atomic_load(&cq[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 6) == chunk) __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    float s0[QH][4];
+    unsigned int live0 = 0u;
+    int64_t i0 = draw();
+    if (i0 >= 0) {
+        i0 += lane;
+        if (4 * i0 < a.npad) live0 = score_quad(i0, s0);
+    }
     // ---- everybody: thread t fetches the threshold word of query t
     if (tid < nq) {
         unsigned long long v;
@@ -260,14 +320,8 @@ __global__ __launch_bounds__(HDB_BITS_THREADS) void hdb_bits_fused_kernel(BitsAr
     for (int qq = 0; qq < QH; ++qq) thr[qq] = qq < nq ? xthr[qq] : INFINITY;
 
     HDB_XSTAMP(4);
-    // ---- filter: the pass over all sign bits (thread-interleaved static split; a chunked hand-out from a global counter needs a
-    // barrier per chunk and chunks of >= 196 KB per workgroup: 8 us granules that cost more than the skew they remove,
-    // profiles/r3_bits_timeline.txt)
-    for (int64_t j = b * HDB_BITS_THREADS + tid; j < a.ntiles * 4; j += G * HDB_BITS_THREADS) {
-        const int64_t i = j;
-        if (4 * i >= a.npad) continue;
-        float s[QH][4];
-        const unsigned int livebits = score_quad(i, s);
+    // ---- filter: rows at or above the threshold go to the per-query candidate lists
+    auto keep = [&](int64_t i, const float (&s)[QH][4], unsigned int livebits) __attribute__((always_inline)) {
 #pragma unroll
         for (int qq = 0; qq < QH; ++qq)
 #pragma unroll
@@ -278,7 +332,19 @@ __global__ __launch_bounds__(HDB_BITS_THREADS) void hdb_bits_fused_kernel(BitsAr
                     if (pos < a.cap) a.cand[(int64_t)qq * a.cap + pos] = hdb_pack(s[qq][u], (uint32_t)row);
                 }
             }
-    }
+    };
+    if (live0) keep(i0, s0, live0);
+    if (i0 >= 0)
+        for (;;) {
+            const int64_t p = draw();
+            if (p < 0) break;
+            const int64_t i = p + lane;
+            if (4 * i < a.npad) {                         // (no `continue`: draw() is a wave-level step)
+                float s[QH][4];
+                const unsigned int livebits = score_quad(i, s);
+                keep(i, s, livebits);
+            }
+        }
 
     HDB_XSTAMP(5);
     // ---- finish: drain, release, arrive; wait for everybody; owners sort their queries

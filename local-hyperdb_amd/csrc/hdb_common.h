@@ -92,6 +92,19 @@ struct BatchArgs {
 };
 
 // Arguments of the single-launch top-k of the bit metrics (hdb_bits_fused.hip): 1-4 hamming / jaccard queries in one launch.
+// Sign bits of the stored rows (hamming / jaccard): blocks of 256 rows, word-major inside a block -- [block][w][256 rows] -- so the
+// W x 1 KiB of a block are one contiguous piece (a wave step of the bit scans: 64 lanes x 16 B per word) and a pass streams the
+// array front to back.  (Round 2 kept whole word planes, [w][npad]: a wave step touched W places 4*npad bytes apart and the
+// pass over 480 MB ran at 5.3-5.6 TB/s.)  npad is a multiple of 256.
+#define HDB_BITS_BLOCK 256
+__host__ __device__ __forceinline__ int64_t hdb_bits_word(int64_t row, int w, int W) {
+    return (((row >> 8) * W + w) << 8) + (row & 255);
+}
+// the uint4 (four consecutive rows) of row quad i, word w
+__device__ __forceinline__ const uint4* hdb_bits_quad(const uint32_t* bits, int64_t i, int w, int W) {
+    return reinterpret_cast<const uint4*>(bits + (((i >> 6) * W + w) << 8) + 4 * (i & 63));
+}
+
 struct BitsArgs {
     const uint32_t* bits; int64_t npad; int32_t W;
     int64_t n; int32_t d;

@@ -297,8 +297,8 @@ __global__ __launch_bounds__(64) void hdb_qprep_kernel(const Acc* Q, int nq, int
 
 // ------------------------------------------------------------------------------------------------
 // Hamming (ranking_algorithm.py:116-147): binarise by x > 0, similarity = d - popcount(v ^ q).
-// Sign bits are packed once per matrix, word-major: bits[w][row] (row pitch npad, multiple of 4)
-// so that a scan thread handling rows 4i..4i+3 reads one uint4 per word, fully coalesced.
+// Sign bits are packed once per matrix in blocks of 256 rows, word-major inside a block (hdb_bits_word, hdb_common.h): a scan
+// thread handling rows 4i..4i+3 reads one uint4 per word, fully coalesced, and a wave's W loads are one contiguous piece.
 // Algorithmic bytes per row = 4 * ceil(d/32).
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -312,8 +312,9 @@ __global__ __launch_bounds__(256) void hdb_signpack_kernel(const T* V, int64_t n
             const bool pos = (e < d) && (hdb_to_f(V[r * (int64_t)d + e]) > 0);
             const unsigned long long m = __ballot(pos);
             if (lane == 0) {
-                bits[(int64_t)(e0 >> 5) * npad + r] = (uint32_t)m;
-                if (e0 + 32 < d) bits[(int64_t)((e0 >> 5) + 1) * npad + r] = (uint32_t)(m >> 32);
+                const int W = (d + 31) >> 5;
+                bits[hdb_bits_word(r, e0 >> 5, W)] = (uint32_t)m;
+                if (e0 + 32 < d) bits[hdb_bits_word(r, (e0 >> 5) + 1, W)] = (uint32_t)(m >> 32);
             }
         }
     }
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(256) void hdb_hamming_kernel(ScanArgs a, const uint
 #pragma unroll
             for (int u = 0; u < 4; ++u) { mism[qq][u] = 0; uni[qq][u] = 0; }
         for (int w = 0; w < W; ++w) {
-            const uint4 v = *reinterpret_cast<const uint4*>(bits + (int64_t)w * npad + 4 * i);
+            const uint4 v = *hdb_bits_quad(bits, i, w, W);
             const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int qq = 0; qq < QH; ++qq) {
