@@ -217,7 +217,7 @@ void hdb_group_destroy(hdb_group* g);
  * Options:  max_blocks (0 = automatic grid of the row scans), force_exact (1: always the exact selection),
  *   sample_target (expected survivors of the sampled threshold, 0 = automatic), use_mfma (0: VALU scans only),
  *   mfma_min_q (smallest batch that takes the MFMA scan on fp16 matrices, default 1), mfma_variant (16 | 32: MFMA
- *   shape of the 256-query pass), bits_fused (0: hamming / jaccard always through the exact selection),
+ *   shape of the 256-query pass), bits_fused (0: hamming / jaccard always through the exact selection; 3: one-query calls on 1M+ rows keep the six launches),
  *   host_direct (0: hdb_topk_host always copies through a device record), exact_bytes (score workspace cap of
  *   the exact path), finalize_threads (256 | 512 | 1024), profile (1: HIP events around the pass over V),
  *   use_fused (0: never the single-launch pipeline), fused_timeout_us (bound of its in-kernel spins, default 2000),

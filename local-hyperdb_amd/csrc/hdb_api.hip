@@ -549,7 +549,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
                       hdb_mfma_supported(ix->dtype, ix->d, is_pearson ? (int)HDB_COSINE : metric);
     // 1-4 dot / cosine queries, k <= 128: one launch does everything (hdb_mfma_fused.h; fp16 on the matrix cores,
     // float32 in the VALU from the same staged tiles)
-    const bool fused_shape = ix->use_fused && !exact && !small && k <= HDB_MAX_K && dev_status != nullptr && !is_ham && !is_pearson &&
+    const bool fused_shape = ix->use_fused && !exact && !small && k <= HDB_MAX_K && dev_status != nullptr && !is_ham &&
                              hdb_mfma_fused_supported(ix->dtype, ix->d, metric, nq, kk) && (ix->dtype == HDB_F32 || mfma) &&
                              // float32 d = 512 streams 32-KiB tiles (16 rows): below ~3 GB the five-kernel VALU pipeline is
                              // 2-5 % faster end to end (200 vs 210 us at 0.5 M rows, 376 vs 385 at 1 M; 728 vs 687 at 2 M)
@@ -607,12 +607,12 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     // the MFMA scan multiplies with fp16 queries: written by the same kernel (pearson converts its centred copy later)
     const bool f16_queries = mfma && ix->dtype == HDB_F16;          // fp32 matrices multiply with the float32 queries as they are
     const bool q16_in_prep = f16_queries && !is_pearson && !full_sort;
-    // (one query on a large matrix stays with the six launches: their 32-waves-per-CU scan streams 5-7 % faster than the scan
-    // inside the 16-wave persistent workgroups -- 124 vs 132 us at N=10M, 63 vs 66 at 1.25M, but 52 vs 46 at 250k rows; two to
-    // four queries: 200 vs 140 us at N=10M, profiles/r3_bits_single_launch_vs_six.txt)
+    // hamming / jaccard: the single launch for every call (with the two-level hand-out of the pass: one query 120-124 vs 125-132 us
+    // for the six launches at N=10M, 78 vs 77 at 5M, 60 vs 63 at 1.25M, 44 vs 52 at 250k rows; four queries 135 vs 172 at N=10M --
+    // profiles/r3_bits_variants.txt; bits_fused = 3 keeps one-query calls on 1M+ rows with the six launches, for comparison)
     const bool bits1_pre = ix->use_fused && ix->bits_fused && is_ham && !exact && !small && !full_sort && !f64 && dev_status != nullptr &&
-                           hdb_bits_fused_supported(metric, 1, W, kk) && (nq >= 2 || n < 1000000 || ix->bits_fused == 2);
-                           // (the single launch prepares its queries itself; bits_fused = 2 forces it)
+                           hdb_bits_fused_supported(metric, 1, W, kk) && (nq >= 2 || n < 1000000 || ix->bits_fused != 3);
+                           // (the single launch prepares its queries itself)
     if (!fused && !batch1 && !bits1_pre) LAUNCH_TRY(hdb_launch_qprep(dev_Q, nq, ix->d, f64, qinv, qsq, qnan, q16_in_prep ? q16 : nullptr, qscl, st));
     if (is_ham) {
         rc = ensure_bits(ix, st); if (rc) return rc;
@@ -622,7 +622,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     int metric_eff = metric;
     if (is_pearson) {
         rc = ensure_pscale(ix, st); if (rc) return rc;
-        LAUNCH_TRY(hdb_launch_qcentre(dev_Q, nq, ix->d, f64, qc, qinv, st));     // qinv <- 1/sd_q
+        if (!fused) LAUNCH_TRY(hdb_launch_qcentre(dev_Q, nq, ix->d, f64, qc, qinv, st));     // qinv <- 1/sd_q (the single launch centres its queries itself)
         Qeff = qc; metric_eff = HDB_COSINE;
     }
     if (full_sort) {
@@ -683,6 +683,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
         ScanArgs a; base_args(ix, a, dev_Q, metric);
         a.bias = bias_eff; a.mask = nullptr;
         if (metric == HDB_EUCLIDEAN) a.inv_norm = ix->sqnorm;          // the per-row aux value of the euclidean expansion
+        if (is_pearson) a.inv_norm = ix->pscale;                       // 1/(sd_v d); the kernel centres the queries itself
         a.ntiles = (n + tile_rows - 1) / tile_rows;
         a.thr = thr; a.cnt = cnt; a.cand = cand; a.nq = nq;
         FusedArgs fa; memset(&fa, 0, sizeof(fa));

@@ -96,7 +96,8 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     // to 2 queries, inside the candidate-list region, which then keeps 256 entries) and wave 0 reads one fragment per k-step
     constexpr bool BLDS = !VALU && D > 768;
     constexpr int CB = BLDS ? 256 : HDB_MFMA_CB;   // LDS candidate-list entries in use
-    constexpr bool AUX0 = METRIC != 0;
+    constexpr bool COSLIKE = METRIC == 1 || METRIC == 3;     // pearson = cosine on the centred query with the row scale 1/(sd_v d) and 1/sd_q (hdb_scan.hip)
+    constexpr bool AUX0 = COSLIKE || (METRIC == 2 && sizeof(E) == 2);      // cosine: 1/||v||; pearson: 1/(sd_v d); euclidean on the matrix cores: ||v||^2
     constexpr int NGL = R * CPR / 256;          // pieces per staging wave and tile (waves 4-7)
     constexpr int NLOADA = NGL;
     constexpr int NLOADB = NGL + (AUX0 ? 1 : 0) + (HAS_BIAS ? 1 : 0);
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     static_assert(R % MF == 0 && R <= 64 && (R * CPR) % 256 == 0 && ROWB % 256 == 0, "tile geometry");
     static_assert(!BLDS || (RT == 1 && 2 * D * 2 + 2048 <= HDB_MFMA_CB * 8), "LDS-resident fragments: 16-row tiles, two queries behind 2 KiB of list");
     static_assert(!VALU || (NJ * VQ <= 12 && (NP % 2 == 0 || NP == 1)), "float32 flavour: query chunks in registers, one or two computing waves");
-    static_assert(METRIC == 0 || METRIC == 1 || (METRIC == 2 && !VALU), "dot / cosine; euclidean (||v||^2 + ||q||^2 - 2 v.q, aux0 = ||v||^2) on the matrix cores only");
+    static_assert(METRIC >= 0 && METRIC <= 3, "dot / cosine / euclidean / pearson (matrix cores: ||v||^2 + ||q||^2 - 2 v.q with aux0 = ||v||^2; float32 VALU flavour: the direct sum of (v - q)^2 of hdb_scan.hip, nothing to re-score)");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* auxbuf = reinterpret_cast<float*>(smem + 3 * STAGE);                    // [3 stages][2][64]
@@ -258,6 +259,16 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     const unsigned int qpar_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(qpar);
     const unsigned int qlds_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(qlds);
     if (w < nq) {
+        if constexpr (METRIC == 3) {                 // centre the query exactly as hdb_qcentre_kernel does (same partial sums, same tree)
+            float sm = 0.f;
+#pragma unroll
+            for (int u = 0; u < QPL; ++u) sm += qreg[u];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+            const float mean = sm / (float)D;
+#pragma unroll
+            for (int u = 0; u < QPL; ++u) qreg[u] = lane + 64 * u < D ? qreg[u] - mean : 0.f;
+        }
         float ss = 0.f, amax = 0.f;
 #pragma unroll
         for (int u = 0; u < QPL; ++u) { ss = fmaf(qreg[u], qreg[u], ss); amax = fmaxf(amax, fabsf(qreg[u])); }   // as hdb_qprep_kernel
@@ -275,8 +286,9 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
             }
         }
         if (lane == 0) {
-            const float qinv = (ss == 0.f) ? 1.0f : 1.0f / sqrtf(ss);
-            hdb_lds_st32(qpar_addr + (unsigned int)w * 4u, (METRIC == 1 ? qinv : 1.0f) * (1.f / scale));
+            float qinv = (ss == 0.f) ? 1.0f : 1.0f / sqrtf(ss);
+            if constexpr (METRIC == 3) { const float sd = sqrtf(ss / (float)D); qinv = (sd == 0.f) ? __builtin_nanf("") : 1.0f / sd; }   // 1/sd_q, NaN for a constant query (:107-111)
+            hdb_lds_st32(qpar_addr + (unsigned int)w * 4u, (COSLIKE ? qinv : 1.0f) * (1.f / scale));
             if (METRIC == 2) hdb_lds_st32(qpar_addr + (unsigned int)(3 * HDB_FUSED_MAXQ + w) * 4u, ss);      // ||q||^2
             hdb_lds_st32(qpar_addr + (unsigned int)(HDB_FUSED_MAXQ + w) * 4u, (ss != ss) ? 1.f : 0.f);
             hdb_lds_st32(qpar_addr + (unsigned int)(2 * HDB_FUSED_MAXQ + w) * 4u, __builtin_nanf(""));      // threshold: none yet
@@ -423,7 +435,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
             for (int q = 0; q < VQ; ++q) {
                 const float x = tv[k2][q];
                 if (q < nq && (l16 & 3) == 0 && x >= thr_q[q] && row < n_rows && !(HAS_BIAS && x == -INFINITY)) {
-                    const float sc = hdb_canon(HAS_BIAS ? x : x * qmul[q]);
+                    const float sc = hdb_canon((HAS_BIAS || METRIC == 2) ? x : x * qmul[q]);
                     unsigned int pos;
                     asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pos) : "v"(ctl_addr), "v"(1u) : "memory");
                     const unsigned long long ent = hdb_pack(sc, (uint32_t)row);
@@ -760,7 +772,10 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
 #pragma unroll
                                 for (int u = 0; u < 4; ++u)
 #pragma unroll
-                                    for (int e = 0; e < 4; ++e) accv[u][q] = fmaf(raw[j][u][e], qv[q][j0 + j][e], accv[u][q]);
+                                    for (int e = 0; e < 4; ++e) {
+                                        if constexpr (METRIC == 2) { const float df = raw[j][u][e] - qv[q][j0 + j][e]; accv[u][q] = fmaf(df, df, accv[u][q]); }
+                                        else accv[u][q] = fmaf(raw[j][u][e], qv[q][j0 + j][e], accv[u][q]);
+                                    }
                     }
                     const int rloc = 16 * pp + 4 * g4 + u_own;             // the row this lane owns after the butterfly
                     const float a0 = AUX0 ? ax0[rloc] : 1.f;
@@ -768,7 +783,12 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
 #pragma unroll
                     for (int q = 0; q < VQ; ++q) {
                         const float dot = hdb_rows4_sum(accv[0][q], accv[1][q], accv[2][q], accv[3][q], l16);
-                        const float rawv = METRIC == 1 ? dot * a0 : dot;
+                        if constexpr (METRIC == 2) {          // hdb_emit's expression (hdb_scan.hip): 1 / (1 + ||v - q||), then the bias
+                            const float sim = 1.f / (1.f + sqrtf(dot));
+                            pend[k2][q] = HAS_BIAS ? sim + b0 : sim;
+                            continue;
+                        }
+                        const float rawv = COSLIKE ? dot * a0 : dot;
                         // rounding steps of hdb_emit (hdb_scan.hip): product rounded, THEN the bias added -- the empty asm keeps
                         // hipcc from contracting the two into one fma, so both pipelines return bit-identical scores
                         float scaled = rawv * qmul[q];
@@ -934,7 +954,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                                 const float d2 = fmaxf(fmaf(-2.f * qinv_l, dot, aj[j] + qsq_l), 0.f);
                                 acc[rt][j] = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_sqrtf(d2)) + (HAS_BIAS ? bj[j] : 0.f);
                             } else {
-                                const float raw = METRIC == 1 ? dot * aj[j] : dot;
+                                const float raw = COSLIKE ? dot * aj[j] : dot;
                                 acc[rt][j] = HAS_BIAS ? fmaf(raw, qinv_l, bj[j]) : raw;
                             }
                         }
@@ -1015,7 +1035,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
             // euclidean scores come from ||v||^2 + ||q||^2 - 2 v.q, which cancels when v ~ q: candidates closer than 5 % of
             // ||q||^2 are re-scored from the stored row with the direct difference (hdb_rescore_euclid_kernel, reference :49)
             auto rescore = [&](unsigned long long* buf, uint32_t nc) {
-                if constexpr (METRIC == 2) {
+                if constexpr (METRIC == 2 && sizeof(E) == 2) {
                     const float* qv = f.Qraw + (int64_t)q * D;
                     const float close2 = 0.05f * ssq;
                     const E* Vr = static_cast<const E*>(a.V);
@@ -1083,7 +1103,8 @@ static int launch_fused(const ScanArgs& a, const FusedArgs& f, int blocks, hipSt
     const bool bias = a.bias != nullptr;
     if (a.metric == HDB_DOT) return bias ? launch_fused_one<E, VQ, D, R, 0, true>(a, f, nullptr, blocks, st) : launch_fused_one<E, VQ, D, R, 0, false>(a, f, nullptr, blocks, st);
     if (a.metric == HDB_COSINE) return bias ? launch_fused_one<E, VQ, D, R, 1, true>(a, f, a.inv_norm, blocks, st) : launch_fused_one<E, VQ, D, R, 1, false>(a, f, a.inv_norm, blocks, st);
-    if constexpr (sizeof(E) == 2 && D != 768)       // euclidean: a.inv_norm carries ||v||^2 (set by the host); d = 768 spills 3 registers with it
+    if (a.metric == HDB_PEARSON) return bias ? launch_fused_one<E, VQ, D, R, 3, true>(a, f, a.inv_norm, blocks, st) : launch_fused_one<E, VQ, D, R, 3, false>(a, f, a.inv_norm, blocks, st);   // a.inv_norm carries 1/(sd_v d)
+    if constexpr (sizeof(E) == 4 || D != 768)       // euclidean: a.inv_norm carries ||v||^2 (set by the host; unused by the float32 flavour); fp16 d = 768 spills 3 registers with it
         if (a.metric == HDB_EUCLIDEAN) return bias ? launch_fused_one<E, VQ, D, R, 2, true>(a, f, a.inv_norm, blocks, st) : launch_fused_one<E, VQ, D, R, 2, false>(a, f, a.inv_norm, blocks, st);
     return (int)hipErrorNotSupported;
 }

@@ -1,5 +1,5 @@
 // hdb_mfma_fused.hip -- instantiations of the single-launch top-k (hdb_mfma_fused.h) for the fp16 geometries of
-// hdb_mfma.hip: a whole hdb_topk call of 1..4 dot / cosine queries in ONE kernel.
+// hdb_mfma.hip: a whole hdb_topk call of 1..4 dot / cosine / pearson queries (one euclidean query) in ONE kernel.
 #include "hdb_mfma_fused.h"
 
 extern "C" int hdb_mfma_tile_rows(int dtype, int d);
@@ -19,8 +19,10 @@ extern "C" int hdb_mfma_fused_supported(int dtype, int d, int metric, int nq, ui
     // three registers (those calls take the batched single launch, hdb_mfma_kernel.h MODE 2)
     // (euclidean, 2-4 queries: wave 0 pays sqrt + rcp on all 16 MFMA columns -- 199 vs 182 us at N=1.25M d=384 with four queries; those
     // calls take the batched single launch, where eight waves share the epilogue)
-    const bool euclid = metric == HDB_EUCLIDEAN && dtype == HDB_F16 && d != 768 && nq == 1;
-    return shape && (metric == HDB_DOT || metric == HDB_COSINE || euclid) && nq >= 1 && nq <= maxq && kk <= 128;
+    // float32 (round 3): the VALU flavour accumulates (v - q)^2 directly, as hdb_scan.hip does -- no cancellation, nothing to
+    // re-score, one or two queries like dot / cosine
+    const bool euclid = metric == HDB_EUCLIDEAN && ((dtype == HDB_F16 && d != 768 && nq == 1) || dtype == HDB_F32);
+    return shape && (metric == HDB_DOT || metric == HDB_COSINE || metric == HDB_PEARSON || euclid) && nq >= 1 && nq <= maxq && kk <= 128;
 }
 
 // bytes of the persistent control block: 64 words of counters + the granules

@@ -594,7 +594,7 @@ __global__ __launch_bounds__(64) void hdb_qcentre_kernel(const Acc* Q, int nq, i
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     const Acc mean = s / Acc(d);
     Acc v = Acc(0);
-    for (int e = threadIdx.x; e < d; e += 64) { const Acc c = Q[(int64_t)q * d + e] - mean; Qc[(int64_t)q * d + e] = c; v += c * c; }
+    for (int e = threadIdx.x; e < d; e += 64) { const Acc c = Q[(int64_t)q * d + e] - mean; Qc[(int64_t)q * d + e] = c; v = fma(c, c, v); }   // (explicit: hdb_mfma_fused.h repeats it)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     if (threadIdx.x == 0) { const Acc sd = sqrt(v / Acc(d)); qscale[q] = (sd == Acc(0)) ? NAN : (float)(Acc(1) / sd); }

@@ -1329,7 +1329,7 @@ def test_fuzz_gpu_against_oracle(orc):
 @pytest.mark.parametrize("n,d", [(8193, 384), (8200 + 63, 256), (50_000, 768), (400_000, 256), (1_300_001, 384),
                                  (60_001, 1024), (300_000, 1536), (100_003, 1408), (150_000, 1152)])
 def test_single_launch_pipeline_equals_multi_kernel_and_oracle(orc, n, d):
-    """Every call shape the fused kernel takes (1-4 queries, dot / cosine, k <= 128, bias, row mask, ragged last tile,
+    """Every call shape the fused kernel takes (1-4 queries, dot / cosine / pearson, one euclidean query, k <= 128, bias, row mask, ragged last tile,
     grids smaller than the CU count, static and counter-fed tile chunks) returns exactly what the five-kernel pipeline
     and the on-device exact selection return; one case per shape is checked against the oracle's float64 scores."""
     import torch
@@ -1344,7 +1344,7 @@ def test_single_launch_pipeline_equals_multi_kernel_and_oracle(orc, n, d):
     try:
         bias = torch.rand(n, generator=torch.Generator().manual_seed(3)).float().cuda() * 0.2
         mask = (torch.rand(n, generator=torch.Generator().manual_seed(4)) < 0.3).to(torch.uint8).cuda()
-        for metric in ("cosine_similarity", "dot_product", "euclidean_metric"):
+        for metric in ("cosine_similarity", "dot_product", "euclidean_metric", "pearson_correlation"):
             mid = METRIC_IDS[metric]
             for setup in ("plain", "bias", "mask", "mask+bias"):
                 ix.set_bias(bias if "bias" in setup else None)
@@ -1356,7 +1356,8 @@ def test_single_launch_pipeline_equals_multi_kernel_and_oracle(orc, n, d):
                     if metric == "euclidean_metric" and (d == 768 or nq > 1):
                         single = False                         # (d = 768: three registers short; 2-4 queries: the batched launch is faster)
                     # (what this kernel does not take goes to the batched single launch, stat 2: hdb_mfma_kernel.h MODE 2)
-                    assert ix.stat("fused") == (1 if single else 2) and ix.stat("path") == 1 and int(fst.abs().sum().item()) == 0, (metric, setup, nq, k)
+                    other = 0 if metric == "pearson_correlation" else 2     # (pearson batches: the five kernels on the centred queries)
+                    assert ix.stat("fused") == (1 if single else other) and ix.stat("path") == 1 and int(fst.abs().sum().item()) == 0, (metric, setup, nq, k)
                     ix.set_option("use_fused", 0)
                     ui, us, ust = ix.topk_device(Q[:nq], k, mid)
                     assert ix.stat("fused") == 0
@@ -1554,8 +1555,8 @@ def test_single_launch_pipeline_winners_in_parked_tiles(orc, dt):
 
 @pytest.mark.parametrize("n,d", [(8193, 384), (70_001, 128), (250_000, 256), (400_003, 384), (1_600_001, 512), (90_003, 768), (300_000, 768)])
 def test_single_launch_pipeline_float32(orc, n, d):
-    """float32 matrices (the reference's default fp_precision, BASELINE config 2): 1-2 dot / cosine queries run as one launch
-    whose float32 dot products are computed in the VALU from the staged tiles -- bit-identical to the five-kernel VALU
+    """float32 matrices (the reference's default fp_precision, BASELINE config 2): 1-2 dot / cosine / euclidean queries run as one
+    launch whose float32 sums are computed in the VALU from the staged tiles -- bit-identical to the five-kernel VALU
     pipeline and the exact selection (same accumulation order, same rounding steps), and within 1e-5 of the oracle."""
     import torch
     from hyperdb._native import GpuIndex, METRIC_IDS
@@ -1568,7 +1569,7 @@ def test_single_launch_pipeline_float32(orc, n, d):
     try:
         bias = torch.rand(n, generator=torch.Generator().manual_seed(5)).float().cuda() * 0.2
         mask = (torch.rand(n, generator=torch.Generator().manual_seed(6)) < 0.4).to(torch.uint8).cuda()
-        for metric in ("cosine_similarity", "dot_product"):
+        for metric in ("cosine_similarity", "dot_product", "euclidean_metric", "pearson_correlation"):      # euclidean: the direct sum of (v - q)^2, as hdb_scan.hip
             mid = METRIC_IDS[metric]
             for setup in ("plain", "bias", "mask+bias"):
                 ix.set_bias(bias if "bias" in setup else None)
@@ -1590,6 +1591,9 @@ def test_single_launch_pipeline_float32(orc, n, d):
                 assert ix.stat("fused") == 1
                 orc.check_topk(idx[0], sc[0], V, Q[qi], metric, 100, tol=1e-5)
         ix.topk_device(Q[:3], 10, METRIC_IDS["dot_product"]); assert ix.stat("fused") == 0      # three float32 queries: five-kernel pipeline
+        if not (d == 512 and n < 1_500_000):
+            idx, sc = ix.topk(V[11:12].copy(), 3, METRIC_IDS["euclidean_metric"])                 # an exact duplicate of two stored rows
+            assert ix.stat("fused") == 1 and idx[0][0] == 11 and idx[0][1] == n - 1 and sc[0][0] == 1.0 and sc[0][1] == 1.0
     finally:
         ix.close()
 
@@ -1745,7 +1749,7 @@ def test_bits_single_launch_equals_multi_kernel_and_exact(orc, dt, n, d):
                 for nq, k in ((1, 100), (2, 1), (3, 128), (4, 37), (7, 10)):
                     ix.set_option("use_fused", 1)
                     fi, fs, fst = ix.topk_device(Q[:nq], k, mid)
-                    assert ix.stat("fused") == (3 if (nq >= 2 or n < 1_000_000) else 0) and ix.stat("path") == 1, (metric, setup, nq, k)
+                    assert ix.stat("fused") == 3 and ix.stat("path") == 1, (metric, setup, nq, k)
                     ix.set_option("use_fused", 0)
                     ui, us, ust = ix.topk_device(Q[:nq], k, mid)
                     assert ix.stat("fused") == 0
@@ -1764,8 +1768,9 @@ def test_bits_single_launch_equals_multi_kernel_and_exact(orc, dt, n, d):
                 orc.check_topk(idx[qi], sc[qi], Vh, Q[qi].cpu().numpy(), metric, 100, tol=0.0 if metric == "hamming_distance" else 1e-6)
             if metric == "hamming_distance":
                 assert idx[1][0] == n // 2 and sc[1][0] == d
-        ix.set_option("bits_fused", 2)                   # force the single launch for one query too
+        ix.set_option("bits_fused", 3)                   # one query on a large matrix through the six launches (comparison setting)
         fi, fs, fst = ix.topk_device(Q[:1], 50, METRIC_IDS["hamming_distance"])
+        assert ix.stat("fused") == (0 if n >= 1_000_000 else 3)
         ei, es, _ = ix.topk_device(Q[:1], 50, METRIC_IDS["hamming_distance"], exact=True)
         assert ix.stat("path") == 2 and (int(fst[0].item()) != 0 or (torch.equal(fi, ei) and torch.equal(fs, es)))
         ix.set_option("bits_fused", 1)
