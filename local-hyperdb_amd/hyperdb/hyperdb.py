@@ -46,6 +46,8 @@ import string
 from collections import OrderedDict
 from contextlib import closing
 
+import math
+from operator import itemgetter
 import numpy as np
 import torch
 
@@ -325,7 +327,7 @@ class HyperDB:
             q = np.asarray(self._embed([query_input]))
         elif isinstance(query_input, (list, np.ndarray, tuple)):
             q = np.array(query_input)
-            if not (np.issubdtype(q.dtype, np.number)):
+            if q.dtype.kind not in "fiuc":                     # (np.issubdtype(q.dtype, np.number) at a tenth of its cost)
                 raise ValueError("Numeric array-like query_input expected.")
         else:
             raise ValueError("query_input must be either a string or a numeric array-like object.")
@@ -564,7 +566,8 @@ class HyperDB:
             raise ValueError(f"Invalid metric '{metric}'. Supported: " + ", ".join(f"'{m}'" for m in _METRICS))
         ranking._validate_metric(metric)
         ix = self._index
-        if ix.has_nan or np.isnan(Q).any():
+        # (one query: a NaN anywhere makes q.q a NaN -- a dot product instead of an isnan pass and a reduction)
+        if ix.has_nan or (math.isnan(float(np.dot(Q[0], Q[0]))) if len(Q) == 1 and Q.dtype.kind == "f" else bool(np.isnan(Q).any())):
             raise ValueError(ranking.NAN_MESSAGE)
         masks, n_avail, keep = self._mask_for(filters)
         if n_avail == 0:
@@ -590,12 +593,17 @@ class HyperDB:
         out = []
         documents, sources = self.documents, self.source_indices
         for qi in range(len(Q)):
-            rows = idx[qi][idx[qi] >= 0]
+            rows = idx[qi]
+            if len(rows) and rows[-1] < 0:                        # fewer than k rows exist: the tail is padded with -1
+                rows = rows[rows >= 0]
             docs = self._docs_of_rows(rows).tolist()
             if not return_similarities:
                 out.append([documents[r] for r in docs])
             elif n_avail == 1:                                    # one row left: the reference's scores come back 2-D (:191)
                 out.append([(documents[r], np.array([float(sc[qi][j])]), sources[r]) for j, r in enumerate(docs)])
+            elif len(docs) > 1:                                   # C-level gathers instead of a Python loop over the k results
+                pick = itemgetter(*docs)
+                out.append(list(zip(pick(documents), sc[qi].tolist(), pick(sources))))
             else:
                 out.append([(documents[r], s_, sources[r]) for r, s_ in zip(docs, sc[qi].tolist())])
         return out
