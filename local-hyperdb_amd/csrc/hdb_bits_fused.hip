@@ -51,6 +51,15 @@ typedef __attribute__((address_space(1))) unsigned long long hdb_bgu64;
 #define HDB_BITS_TAIL 1                  // the last ~15 % of the pass is handed out in quarter chunks (tools/exp_bits_variants.py: 5M rows 83 -> 78 us,
                                          // four queries -2..3 %; 8 waves per workgroup instead of 16: +5..20 %)
 #endif
+#ifndef HDB_BITS_TAILDIV
+#define HDB_BITS_TAILDIV 4               // tail chunks = a chunk / this
+#endif
+#ifndef HDB_BITS_TAILPCT
+#define HDB_BITS_TAILPCT 15              // share of the pass handed out in tail chunks
+#endif
+#ifndef HDB_BITS_PREF
+#define HDB_BITS_PREF 1                  // the next chunk is asked for when draw number 1 (1) or np / 2 (2) of the current one is taken
+#endif
 #define HDB_BITS_WAVES (HDB_BITS_THREADS / 64)
 #define HDB_BITS_MAXW 512
 
@@ -260,11 +269,11 @@ __global__ __launch_bounds__(HDB_BITS_THREADS) void hdb_bits_fused_kernel(BitsAr
     // wave, workgroups differed by 19 us, profiles/r3_bits_timeline.txt).
     uint32_t* const cq = xflag + 8;                              // [0] {chunk << 6 | draws}, [1] prefetched chunk + 1
     constexpr uint32_t ENDC = 0x03FFFFFFu;
-    constexpr uint32_t NPC = HDB_BITS_WAVES, TP = NPC / 4;          // pieces per chunk, per quarter chunk of the tail
+    constexpr uint32_t NPC = HDB_BITS_WAVES, TP = NPC / HDB_BITS_TAILDIV;          // pieces per chunk, per quarter chunk of the tail
     const uint32_t npieces = (uint32_t)((a.ntiles * 4 + 63) / 64);
     uint32_t nbig = (npieces + NPC - 1) / NPC, nsmall = 0u;
     if (HDB_BITS_TAIL && nbig >= 4u * (uint32_t)G) {
-        nbig = (uint32_t)((uint64_t)npieces * 85 / 100 / NPC);
+        nbig = (uint32_t)((uint64_t)npieces * (100 - HDB_BITS_TAILPCT) / 100 / NPC);
         nsmall = (npieces - nbig * NPC + TP - 1) / TP;
     }
     const uint32_t nchunks = nbig + nsmall;
@@ -277,7 +286,7 @@ __global__ __launch_bounds__(HDB_BITS_THREADS) void hdb_bits_fused_kernel(BitsAr
             if (chunk == ENDC) return -1;
             const uint32_t np = chunk < nbig ? NPC : TP;
             const int64_t p0 = chunk < nbig ? (int64_t)chunk * NPC : (int64_t)nbig * NPC + (int64_t)(chunk - nbig) * TP;
-            if (sub == 1u && lane == 0) {                                  // ask for the chunk after this one
+            if (sub == (HDB_BITS_PREF == 2 ? np / 2 : 1u) && lane == 0) {   // ask for the chunk after this one
                 const uint32_t nx = (uint32_t)G + __hip_atomic_fetch_add(a.ctl + HDB_BATCH_CTL_TILE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&cq[1], nx + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
