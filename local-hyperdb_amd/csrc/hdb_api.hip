@@ -25,7 +25,7 @@ extern "C" {
 int hdb_launch_scan(const ScanArgs* args, int dtype, int mode, int nq_launch, int max_blocks, void* stream);
 int hdb_launch_rownorm(const void* V, int64_t n, int d, int dtype, float* inv_norm, float* sqnorm, int* nan_flag, void* stream);
 int hdb_launch_qprep(const void* Q, int nq, int d, bool f64, float* qinv, float* qsq, int* qnan, void* q16, float* qscl, void* stream);
-int hdb_launch_signpack(const void* V, int64_t n, int d, int dtype, int64_t npad, uint32_t* bits, void* stream);
+int hdb_launch_signpack(const void* V, int64_t n, int d, int dtype, int64_t row0, uint32_t* bits, void* stream);
 int hdb_launch_qsign(const void* Q, int nq, int d, bool f64, int W, uint32_t* qbits, void* stream);
 int hdb_launch_hamming(const ScanArgs* args, int mode, int nq_launch, const uint32_t* bits, int64_t npad, int W,
                        const uint32_t* qbits, void* stream);
@@ -102,10 +102,12 @@ struct hdb_index {
     int64_t bits_npad = 0;
     int W = 0;
     bool bits_valid = false;
+    int64_t bits_done = 0;            // rows [0, bits_done) are packed for the CURRENT matrix (hdb_index_extend keeps them: only the appended rows are packed)
     // pearson per-row scale 1/(sd*d) (owned, lazy)
     float* pscale = nullptr;
     int64_t pscale_rows = 0;
     bool pscale_valid = false;
+    int64_t pscale_done = 0;          // likewise
     // borrowed
     const float* bias = nullptr;
     const uint8_t* mask = nullptr;
@@ -185,8 +187,8 @@ static int build_caches(hdb_index* ix, hipStream_t st) {
     }
     HIP_TRY(hipMemsetAsync(ix->nan_flag, 0, sizeof(int), st));
     if (ix->n > 0) LAUNCH_TRY(hdb_launch_rownorm(ix->V, ix->n, ix->d, ix->dtype, ix->inv_norm, ix->sqnorm, ix->nan_flag, st));
-    ix->bits_valid = false;
-    ix->pscale_valid = false;
+    ix->bits_valid = false; ix->bits_done = 0;         // a new matrix: nothing of the lazy caches survives
+    ix->pscale_valid = false; ix->pscale_done = 0;
     ix->build_stream = st;
     return HDB_OK;
 }
@@ -260,7 +262,7 @@ extern "C" int hdb_index_extend(hdb_index* ix, int64_t new_n, void* stream) {
     const char* tail = (const char*)ix->V + (size_t)old_n * ix->d * elem;
     LAUNCH_TRY(hdb_launch_rownorm(tail, new_n - old_n, ix->d, ix->dtype, ix->inv_norm + old_n, ix->sqnorm + old_n, ix->nan_flag, st));
     ix->n = new_n;
-    ix->bits_valid = false;
+    ix->bits_valid = false;                            // (bits_done / pscale_done stay: the next hamming / pearson call packs the appended rows only)
     ix->pscale_valid = false;
     ix->bias = nullptr; ix->mask = nullptr;            // per-row inputs of the old length no longer apply
     ix->build_stream = st;
@@ -287,7 +289,7 @@ extern "C" int hdb_index_gather(hdb_index* ix, const int64_t* dev_rows, int64_t 
     if (ix->inv_norm) { (void)hipFree(ix->inv_norm); (void)hipFree(ix->sqnorm); }
     ix->inv_norm = inv2; ix->sqnorm = sq2; ix->cache_rows = rows;
     ix->V = dev_V_out; ix->n = m;
-    ix->bits_valid = false; ix->pscale_valid = false;
+    ix->bits_valid = false; ix->pscale_valid = false; ix->bits_done = 0; ix->pscale_done = 0;
     ix->bias = nullptr; ix->mask = nullptr;
     ix->build_stream = st;
     return HDB_OK;
@@ -405,13 +407,19 @@ static bool is_bits_metric(int metric) { return metric == HDB_HAMMING || metric 
 
 static int ensure_pscale(hdb_index* ix, hipStream_t st) {
     if (ix->pscale_valid) return HDB_OK;
+    const size_t elem = ix->dtype == HDB_F16 ? 2 : ix->dtype == HDB_F32 ? 4 : 8;
+    int64_t keep = ix->pscale ? std::min(ix->pscale_done, ix->n) : 0;          // rows whose scale is still good (appended matrix)
     if (ix->n > ix->pscale_rows) {
-        if (ix->pscale) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(ix->pscale)); ix->pscale = nullptr; }
         const int64_t rows = ix->n + ix->n / 4 + 64;
-        HIP_TRY(hipMalloc((void**)&ix->pscale, rows * sizeof(float)));
-        ix->pscale_rows = rows;
+        float* p2 = nullptr;
+        HIP_TRY(hipMalloc((void**)&p2, rows * sizeof(float)));
+        if (keep > 0) HIP_TRY(hipMemcpyAsync(p2, ix->pscale, keep * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (ix->pscale) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(ix->pscale)); }
+        ix->pscale = p2; ix->pscale_rows = rows;
     }
-    if (ix->n > 0) LAUNCH_TRY(hdb_launch_rowstats(ix->V, ix->n, ix->d, ix->dtype, ix->pscale, st));
+    if (ix->n > keep)
+        LAUNCH_TRY(hdb_launch_rowstats((const char*)ix->V + (size_t)keep * ix->d * elem, ix->n - keep, ix->d, ix->dtype, ix->pscale + keep, st));
+    ix->pscale_done = ix->n;
     ix->pscale_valid = true;
     return HDB_OK;
 }
@@ -419,16 +427,26 @@ static int ensure_pscale(hdb_index* ix, hipStream_t st) {
 static int ensure_bits(hdb_index* ix, hipStream_t st) {
     if (ix->bits_valid) return HDB_OK;
     const int W = (ix->d + 31) / 32;
-    const int64_t npad = align_up((size_t)std::max<int64_t>(ix->n, 4), 256);      // whole 256-row blocks (hdb_bits_word)
-    if (!ix->bits || ix->bits_npad < npad || ix->W != W) {
-        if (ix->bits) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(ix->bits)); ix->bits = nullptr; }
-        const int64_t cap = align_up((size_t)(npad + npad / 4), 256);
-        HIP_TRY(hipMalloc((void**)&ix->bits, (size_t)cap * W * sizeof(uint32_t)));
-        ix->bits_npad = cap; ix->W = W;
-    }
     if (W > 512) return fail(HDB_ERR_UNSUPPORTED, "hamming: d > 16384 not supported");
-    HIP_TRY(hipMemsetAsync(ix->bits, 0, (size_t)ix->bits_npad * W * sizeof(uint32_t), st));
-    if (ix->n > 0) LAUNCH_TRY(hdb_launch_signpack(ix->V, ix->n, ix->d, ix->dtype, ix->bits_npad, ix->bits, st));
+    const size_t elem = ix->dtype == HDB_F16 ? 2 : ix->dtype == HDB_F32 ? 4 : 8;
+    const int64_t npad = align_up((size_t)std::max<int64_t>(ix->n, 4), 256);      // whole 256-row blocks (hdb_bits_word)
+    // rows packed before the matrix grew stay where they are: the layout is a sequence of 256-row blocks, so a bigger buffer takes
+    // the old blocks as a prefix (hdb_index_extend / HyperDB.add: the next bit-metric call packs the appended rows only)
+    int64_t keep = (ix->bits && ix->W == W) ? std::min(ix->bits_done, ix->n) : 0;
+    if (!ix->bits || ix->bits_npad < npad || ix->W != W) {
+        const int64_t cap = align_up((size_t)(npad + npad / 4), 256);
+        uint32_t* b2 = nullptr;
+        HIP_TRY(hipMalloc((void**)&b2, (size_t)cap * W * sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(b2, 0, (size_t)cap * W * sizeof(uint32_t), st));
+        if (keep > 0) HIP_TRY(hipMemcpyAsync(b2, ix->bits, (size_t)align_up((size_t)keep, 256) * W * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+        if (ix->bits) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(ix->bits)); }
+        ix->bits = b2; ix->bits_npad = cap; ix->W = W;
+    } else if (keep == 0) {
+        HIP_TRY(hipMemsetAsync(ix->bits, 0, (size_t)ix->bits_npad * W * sizeof(uint32_t), st));
+    }
+    if (ix->n > keep)
+        LAUNCH_TRY(hdb_launch_signpack((const char*)ix->V + (size_t)keep * ix->d * elem, ix->n - keep, ix->d, ix->dtype, keep, ix->bits, st));
+    ix->bits_done = ix->n;
     ix->bits_valid = true;
     return HDB_OK;
 }

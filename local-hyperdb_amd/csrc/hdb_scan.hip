@@ -302,7 +302,7 @@ __global__ __launch_bounds__(64) void hdb_qprep_kernel(const Acc* Q, int nq, int
 // Algorithmic bytes per row = 4 * ceil(d/32).
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void hdb_signpack_kernel(const T* V, int64_t n, int d, int64_t npad, uint32_t* bits) {
+__global__ __launch_bounds__(256) void hdb_signpack_kernel(const T* V, int64_t n, int d, int64_t row0, uint32_t* bits) {      // V: row row0 of the matrix, n rows from there
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
@@ -313,8 +313,8 @@ __global__ __launch_bounds__(256) void hdb_signpack_kernel(const T* V, int64_t n
             const unsigned long long m = __ballot(pos);
             if (lane == 0) {
                 const int W = (d + 31) >> 5;
-                bits[hdb_bits_word(r, e0 >> 5, W)] = (uint32_t)m;
-                if (e0 + 32 < d) bits[hdb_bits_word(r, (e0 >> 5) + 1, W)] = (uint32_t)(m >> 32);
+                bits[hdb_bits_word(row0 + r, e0 >> 5, W)] = (uint32_t)m;
+                if (e0 + 32 < d) bits[hdb_bits_word(row0 + r, (e0 >> 5) + 1, W)] = (uint32_t)(m >> 32);
             }
         }
     }
@@ -470,12 +470,12 @@ extern "C" int hdb_launch_qprep(const void* Q, int nq, int d, bool f64, float* q
     return (int)hipGetLastError();
 }
 
-extern "C" int hdb_launch_signpack(const void* V, int64_t n, int d, int dtype, int64_t npad, uint32_t* bits, void* stream) {
+extern "C" int hdb_launch_signpack(const void* V, int64_t n, int d, int dtype, int64_t row0, uint32_t* bits, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int blocks = hdb_grid_for(n, 4, 4096);
-    if (dtype == HDB_F16) hipLaunchKernelGGL(hdb_signpack_kernel<__half>, dim3(blocks), dim3(256), 0, st, (const __half*)V, n, d, npad, bits);
-    else if (dtype == HDB_F32) hipLaunchKernelGGL(hdb_signpack_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)V, n, d, npad, bits);
-    else hipLaunchKernelGGL(hdb_signpack_kernel<double>, dim3(blocks), dim3(256), 0, st, (const double*)V, n, d, npad, bits);
+    if (dtype == HDB_F16) hipLaunchKernelGGL(hdb_signpack_kernel<__half>, dim3(blocks), dim3(256), 0, st, (const __half*)V, n, d, row0, bits);
+    else if (dtype == HDB_F32) hipLaunchKernelGGL(hdb_signpack_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)V, n, d, row0, bits);
+    else hipLaunchKernelGGL(hdb_signpack_kernel<double>, dim3(blocks), dim3(256), 0, st, (const double*)V, n, d, row0, bits);
     return (int)hipGetLastError();
 }
 

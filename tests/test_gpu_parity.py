@@ -1782,6 +1782,45 @@ def test_bits_single_launch_equals_multi_kernel_and_exact(orc, dt, n, d):
 
 
 # ------------------------------------------------------------------------------------------------
+# 13b. appended rows: the lazy per-row caches (sign bits, pearson scales) are extended, not rebuilt
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt,d", [(np.float16, 384), (np.float32, 100)])
+def test_appended_rows_extend_sign_bits_and_pearson_scales(orc, dt, d):
+    """GpuIndex.append after hamming / jaccard / pearson queries: the next such query packs / scales the appended rows only
+    (hdb_index_extend keeps the 256-row blocks of sign bits and the scales of the old rows) -- results equal a fresh index over
+    all rows bit for bit, across several appends, a growth of the bit buffer and block boundaries."""
+    import torch
+    from hyperdb._native import GpuIndex, METRIC_IDS
+    rng = np.random.default_rng(d)
+    total = 30_011
+    V = rng.standard_normal((total, d)).astype(np.float32).astype(dt)
+    Q = rng.standard_normal((3, d)).astype(np.float32)
+    Q[1] = V[total - 5].astype(np.float32)                       # its best match arrives with the last append
+    cuts = [9_000, 9_001, 9_256, 20_000, total]                  # one row, up to a block boundary, past the 25 % head room, the rest
+    ix = GpuIndex(V[:cuts[0]].copy())
+    try:
+        metrics = ("hamming_distance", "jaccard_similarity", "pearson_correlation")
+        for m in metrics:
+            ix.topk(Q, 10, METRIC_IDS[m])                        # builds the lazy caches on the first rows
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            ix.append(V[lo:hi])
+            fresh = GpuIndex(V[:hi].copy())
+            try:
+                for m in metrics:
+                    for nq in (1, 3):
+                        gi, gs = ix.topk(Q[:nq], 50, METRIC_IDS[m])
+                        fi, fs = fresh.topk(Q[:nq], 50, METRIC_IDS[m])
+                        assert np.array_equal(gi, fi) and np.array_equal(gs, fs), (m, nq, hi)
+            finally:
+                fresh.close()
+        idx, sc = ix.topk(Q[1:2], 5, METRIC_IDS["hamming_distance"])
+        assert idx[0][0] == total - 5 and sc[0][0] == d
+        orc.check_topk(idx[0], sc[0], V, Q[1], "hamming_distance", 5, tol=0.0)
+    finally:
+        ix.close()
+
+
+# ------------------------------------------------------------------------------------------------
 # 14. wide rows on the matrix cores through K slices (hdb_mfma_ksplit.hip): float32 d = 1024 / 1536, fp16 d = 2048 / 3072 / 4096
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dt,n,d,nq", [(np.float32, 40_017, 1536, 64), (np.float32, 30_000, 1024, 17), (np.float16, 50_003, 2048, 64),
