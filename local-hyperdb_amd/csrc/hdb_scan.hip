@@ -307,30 +307,15 @@ __global__ __launch_bounds__(256) void hdb_signpack_kernel(const T* V, int64_t n
     const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * 256) >> 6;
     const int W = (d + 31) >> 5;
-    // A wave packs eight consecutive rows per step (row0 a multiple of 8, as in a full build: rows of one 256-row block): their loads are
-    // issued together, and the sixteen words of a 64-dimension step -- (word 0 | word 1) x eight rows -- leave in ONE store
-    // instruction as two full 32-byte runs (eight consecutive rows of a word are adjacent in the block layout).  One row and one
-    // single-lane store at a time the pass over a 10M x 384 fp16 matrix took 4.8 ms (1.5 TB/s).
-    constexpr int RB = 8;
-    for (int64_t r8 = wave * RB; r8 < n; r8 += nwaves * RB) {
-        for (int e0 = 0; e0 < d; e0 += 64) {
+    for (int64_t r = wave; r < n; r += nwaves) {               // generic d: a row per wave step, 2-byte .. 8-byte loads (eight rows per step
+        for (int e0 = 0; e0 < d; e0 += 64) {                    // with sixteen-lane stores measured no faster: 5.2 vs 4.8 ms at 10M x 384 fp16)
             const int e = e0 + lane;
-            bool pos[RB];
-#pragma unroll
-            for (int u = 0; u < RB; ++u) {
-                const int64_t r = r8 + u;
-                pos[u] = (e < d) && (r < n) && (hdb_to_f(V[(r < n ? r : n - 1) * (int64_t)d + (e < d ? e : 0)]) > 0);
+            const bool pos = (e < d) && (hdb_to_f(V[r * (int64_t)d + e]) > 0);
+            const unsigned long long m = __ballot(pos);
+            if (lane == 0) {
+                bits[hdb_bits_word(row0 + r, e0 >> 5, W)] = (uint32_t)m;
+                if (e0 + 32 < d) bits[hdb_bits_word(row0 + r, (e0 >> 5) + 1, W)] = (uint32_t)(m >> 32);
             }
-            const int u_l = lane & 7, half = (lane >> 3) & 1;          // lanes 0..15: row u_l, word e0 / 32 + half
-            unsigned long long mine = 0ull;
-#pragma unroll
-            for (int u = 0; u < RB; ++u) {
-                const unsigned long long m = __ballot(pos[u]);          // (the same value in every lane)
-                if (u == u_l) mine = m;
-            }
-            const int64_t r = r8 + u_l;
-            const int wd = (e0 >> 5) + half;
-            if (lane < 16 && r < n && wd < W) bits[hdb_bits_word(row0 + r, wd, W)] = (uint32_t)(half ? mine >> 32 : mine);
         }
     }
 }
@@ -530,13 +515,14 @@ extern "C" int hdb_launch_qprep(const void* Q, int nq, int d, bool f64, float* q
 
 extern "C" int hdb_launch_signpack(const void* V, int64_t n, int d, int dtype, int64_t row0, uint32_t* bits, void* stream) {
     hipStream_t st = (hipStream_t)stream;
-    const int blocks = hdb_grid_for((n + 7) / 8, 4, 4096);          // a wave per eight rows
     if (d % 32 == 0 && (reinterpret_cast<uintptr_t>(V) & 15) == 0) {
+        const int blocks = hdb_grid_for((n + 7) / 8, 4, 4096);      // a wave per eight rows
         if (dtype == HDB_F16) hipLaunchKernelGGL(hdb_signpack_wide_kernel<__half>, dim3(blocks), dim3(256), 0, st, (const __half*)V, n, d, row0, bits);
         else if (dtype == HDB_F32) hipLaunchKernelGGL(hdb_signpack_wide_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)V, n, d, row0, bits);
         else hipLaunchKernelGGL(hdb_signpack_wide_kernel<double>, dim3(blocks), dim3(256), 0, st, (const double*)V, n, d, row0, bits);
         return (int)hipGetLastError();
     }
+    const int blocks = hdb_grid_for(n, 4, 4096);
     if (dtype == HDB_F16) hipLaunchKernelGGL(hdb_signpack_kernel<__half>, dim3(blocks), dim3(256), 0, st, (const __half*)V, n, d, row0, bits);
     else if (dtype == HDB_F32) hipLaunchKernelGGL(hdb_signpack_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)V, n, d, row0, bits);
     else hipLaunchKernelGGL(hdb_signpack_kernel<double>, dim3(blocks), dim3(256), 0, st, (const double*)V, n, d, row0, bits);
