@@ -83,7 +83,8 @@ int hdb_index_update(hdb_index* ix, const void* dev_V, int64_t n, void* stream);
  *                     pointer changes, every cache stays valid.
  * hdb_index_extend -- rows [n_old, new_n) were appended behind the existing rows of the current allocation; the
  *                     1/||v||, ||v||^2 and NaN caches are extended over the new rows only (O(new rows), not O(N));
- *                     sign-bit and pearson caches are rebuilt lazily on their next use. */
+ *                     the sign bits and the pearson row scales are extended the same way on their next use (lazy caches:
+ *                     the appended rows only). */
 int hdb_index_rebase(hdb_index* ix, const void* dev_V);
 int hdb_index_extend(hdb_index* ix, int64_t new_n, void* stream);
 
