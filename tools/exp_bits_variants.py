@@ -7,8 +7,8 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'local-hyperdb_amd', 'csrc')
 OUT = os.path.join(ROOT, 'local-hyperdb_amd', 'lib', 'bitsvar')
-# name: (threads per workgroup, tail chunks on/off, chunk / tail chunk, tail share in %, prefetch point)
-VARIANTS = {'q15_p1': (1024, 1, 4, 15, 1), 'h25_p1': (1024, 1, 2, 25, 1), 'h25_p2': (1024, 1, 2, 25, 2), 'h40_p2': (1024, 1, 2, 40, 2), 'q15_p2': (1024, 1, 4, 15, 2)}
+# name: (threads per workgroup, tail chunks on/off, chunk / tail chunk, tail share in %, prefetch point, poll: 0 = sc1 loads, 1 = returning atomics)
+VARIANTS = {'poll_load': (1024, 1, 4, 15, 1, 0), 'poll_atomic': (1024, 1, 4, 15, 1, 1)}
 CHILD = r'''
 import sys, time, json
 sys.path.insert(0, 'local-hyperdb_amd'); sys.path.insert(0, '.')
@@ -17,7 +17,7 @@ from hyperdb._native import GpuIndex, METRIC_IDS
 import bench
 dev = torch.device('cuda', 0)
 out = {}
-for n in (10_000_000, 5_000_000, 2_500_000):
+for n in (10_000_000, 2_500_000, 1_250_000, 250_000):
     V, lo, hi = bench.make_shard(n, 384, torch.float16, 0, 1, dev)
     ix = GpuIndex(V)
     mid = METRIC_IDS['hamming_distance']
@@ -39,10 +39,10 @@ def build():
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     objs = [os.path.join(CSRC, 'obj', f) for f in sorted(os.listdir(os.path.join(CSRC, 'obj'))) if f.endswith('.o') and f != 'hdb_bits_fused.o']
     procs = []
-    for name, (thr, tail, tdiv, tpct, pref) in VARIANTS.items():
+    for name, (thr, tail, tdiv, tpct, pref, poll) in VARIANTS.items():
         o = os.path.join(OUT, name + '.o')
         procs.append(subprocess.Popen([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-pass-failed', f'-DHDB_BITS_THREADS={thr}',
-                                       f'-DHDB_BITS_TAIL={tail}', f'-DHDB_BITS_TAILDIV={tdiv}', f'-DHDB_BITS_TAILPCT={tpct}', f'-DHDB_BITS_PREF={pref}',
+                                       f'-DHDB_BITS_TAIL={tail}', f'-DHDB_BITS_TAILDIV={tdiv}', f'-DHDB_BITS_TAILPCT={tpct}', f'-DHDB_BITS_PREF={pref}', f'-DHDB_BITS_POLL={poll}',
                                        '-c', os.path.join(CSRC, 'hdb_bits_fused.hip'), '-o', o]))
     for p in procs:
         if p.wait(): raise SystemExit('hipcc failed')
@@ -54,7 +54,7 @@ def build():
 
 def run():
     import json
-    for rnd in range(2):
+    for rnd in range(3):
         for name in VARIANTS:
             env = dict(os.environ, HYPERDB_HIP_LIB=os.path.join(OUT, f'lib_{name}.so'))
             r = subprocess.run([sys.executable, '-c', CHILD], env=env, cwd=ROOT, timeout=400, stderr=subprocess.DEVNULL, stdout=subprocess.PIPE, text=True)
