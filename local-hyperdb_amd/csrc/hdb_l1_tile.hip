@@ -28,6 +28,12 @@ __global__ __launch_bounds__(512) void hdb_l1_tile_kernel(ScanArgs a, int nq_end
     static_assert(ROWB % 256 == 0 && (NP == 1 || NP == 2 || NP == 4) && STAGE <= 48 * 1024 && PPL + 1 <= 31, "tile geometry");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* bbuf = reinterpret_cast<float*>(smem + 3 * STAGE);       // [3][64] per-row bias of the staged tiles
+    // survivors wait in LDS per query of the block and reach the global lists with one atomic per block and query (as in hdb_scan.hip:
+    // a returning atomic per survivor on the per-query counters is what short passes spent their time in)
+    constexpr int SCAP = 64;
+    unsigned int* scnt = reinterpret_cast<unsigned int*>(smem + 3 * STAGE + 3 * 64 * 4 + 64);      // [NG * NQH] + [1] flush base
+    unsigned long long* sbuf = reinterpret_cast<unsigned long long*>(smem + 3 * STAGE + 3 * 64 * 4 + 64 + 128);   // [NG * NQH][SCAP]
+    if (MODE == 1 && threadIdx.x < NG * NQH + 1) scnt[threadIdx.x] = 0u;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -152,13 +158,33 @@ __global__ __launch_bounds__(512) void hdb_l1_tile_kernel(ScanArgs a, int nq_end
                     const int ql = qg - a.q0;
                     if (MODE == 0) a.scores[(int64_t)ql * a.ld + row] = s;
                     else if (s >= thr[q] && !(HAS_BIAS && s == -INFINITY)) {
-                        const uint32_t pos = atomicAdd(&a.cnt[ql], 1u);
-                        if (pos < a.cap) a.cand[(int64_t)ql * a.cap + pos] = hdb_pack(s, (uint32_t)row);
+                        const unsigned long long ent = hdb_pack(s, (uint32_t)row);
+                        const int slot = qg - qb0;
+                        const unsigned int lp = atomicAdd(&scnt[slot], 1u);             // LDS
+                        if (lp < (unsigned int)SCAP) sbuf[slot * SCAP + (int)lp] = ent;
+                        else {
+                            const uint32_t pos = atomicAdd(&a.cnt[ql], 1u);
+                            if (pos < a.cap) a.cand[(int64_t)ql * a.cap + pos] = ent;
+                        }
                     }
                 }
             }
         }
         st_cur = st_cur == 2 ? 0 : st_cur + 1;
+    }
+    if (MODE == 1) {
+        __syncthreads();
+        for (int slot = 0; slot < nqb; ++slot) {
+            const unsigned int have = scnt[slot] < (unsigned int)SCAP ? scnt[slot] : (unsigned int)SCAP;      // (block-uniform)
+            if (have == 0u) continue;
+            const int ql = qb0 - a.q0 + slot;
+            if (tid == 0) scnt[NG * NQH] = atomicAdd(&a.cnt[ql], have);
+            __syncthreads();
+            const unsigned int base = scnt[NG * NQH];
+            for (unsigned int e = (unsigned int)tid; e < have; e += 512u)
+                if (base + e < a.cap) a.cand[(int64_t)ql * a.cap + base + e] = sbuf[slot * SCAP + (int)e];
+            __syncthreads();
+        }
     }
 }
 
@@ -166,7 +192,7 @@ __global__ __launch_bounds__(512) void hdb_l1_tile_kernel(ScanArgs a, int nq_end
 template <typename E, int D, int R, int NQH, int MODE, bool HAS_BIAS>
 static int l1_launch_one(const ScanArgs& a, int nq_launch, int blocks, hipStream_t st) {
     auto kern = hdb_l1_tile_kernel<E, D, R, NQH, MODE, HAS_BIAS>;
-    const size_t lds = (size_t)3 * R * D * sizeof(E) + 3 * 64 * 4 + 64;
+    const size_t lds = (size_t)3 * R * D * sizeof(E) + 3 * 64 * 4 + 64 + 128 + (size_t)(8 / (R / 16)) * NQH * 64 * 8;      // tiles, bias, survivor counters and slots
     static unsigned long long attr_done = 0;
     hipError_t e = hdb_lds_attr_once(reinterpret_cast<const void*>(kern), (int)lds, &attr_done);
     if (e != hipSuccess) return (int)e;

@@ -38,9 +38,35 @@ __device__ __forceinline__ float hdb_to_f(__half v) { return __half2float(v); }
 __device__ __forceinline__ float hdb_to_f(float v) { return v; }
 __device__ __forceinline__ double hdb_to_f(double v) { return v; }
 
+// Survivors of a filter pass (MODE 1) wait in LDS, per block and query slot, and reach the global candidate lists with ONE atomic
+// per block and query at the end of the block's tiles.  A returning atomic per survivor on the per-query counters (one cache line:
+// ~88 per us) was what small matrices spent their time in: n = 200k x 100 float32, 16 queries, ~2 k survivors each -- 374 us of
+// filter pass for 11 us of matrix; the N <= 8192 path, where every row survives, likewise (tools/diag_small_valu.py).
+#define HDB_STAGE_CAP 128
+struct HdbStage {
+    unsigned long long buf[4][HDB_STAGE_CAP];      // up to four query slots per block (QT, QH <= 4)
+    unsigned int cnt[4];
+    unsigned int base;
+};
+__device__ __forceinline__ void hdb_stage_init(HdbStage& st) { if (threadIdx.x < 4) st.cnt[threadIdx.x] = 0u; }   // (before a block barrier)
+// every thread of the block, after its last tile; slot s holds the survivors of local query ql0 + s
+__device__ __forceinline__ void hdb_stage_flush(const ScanArgs& a, HdbStage& st, int ql0, int nslots) {
+    __syncthreads();
+    for (int s = 0; s < nslots; ++s) {
+        const unsigned int have = min(st.cnt[s], (unsigned int)HDB_STAGE_CAP);        // (block-uniform)
+        if (have == 0u) continue;
+        if (threadIdx.x == 0) st.base = atomicAdd(&a.cnt[ql0 + s], have);
+        __syncthreads();
+        const unsigned int base = st.base;
+        for (unsigned int e = threadIdx.x; e < have; e += blockDim.x)
+            if (base + e < a.cap) a.cand[(int64_t)(ql0 + s) * a.cap + base + e] = st.buf[s][e];
+        __syncthreads();
+    }
+}
+
 // Shared epilogue: raw row sum -> final score of hyperDB_ranking_algorithm_sort, then store / filter.
 template <int MODE, typename Acc>
-__device__ __forceinline__ void hdb_emit(const ScanArgs& a, int q, int64_t row, int64_t out_i, Acc sum) {
+__device__ __forceinline__ void hdb_emit(const ScanArgs& a, int q, int64_t row, int64_t out_i, Acc sum, HdbStage* stg = nullptr, int slot = 0) {
     float s;
     if (a.metric == HDB_EUCLIDEAN) {
         s = (float)(Acc(1) / (Acc(1) + sqrt(sum)));                       // 1/(1+||v-q||), :49-51
@@ -62,8 +88,13 @@ __device__ __forceinline__ void hdb_emit(const ScanArgs& a, int q, int64_t row, 
     } else {
         const int ql = q - a.q0;
         if (!masked && s >= a.thr[ql]) {
-            const uint32_t pos = atomicAdd(&a.cnt[ql], 1u);
-            if (pos < a.cap) a.cand[(int64_t)ql * a.cap + pos] = hdb_pack(s, (uint32_t)row);
+            const unsigned long long ent = hdb_pack(s, (uint32_t)row);
+            if (stg) {
+                const unsigned int lp = atomicAdd(&stg->cnt[slot], 1u);              // LDS
+                if (lp < HDB_STAGE_CAP) { stg->buf[slot][lp] = ent; return; }
+            }
+            const uint32_t pos = atomicAdd(&a.cnt[ql], 1u);                          // the slot is full: straight to the global list
+            if (pos < a.cap) a.cand[(int64_t)ql * a.cap + pos] = ent;
         }
     }
 }
@@ -80,6 +111,8 @@ __global__ __launch_bounds__(256) void hdb_scan_kernel(ScanArgs a, int nq_end) {
     constexpr int EPC = Elem<T>::EPC;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Acc* qs = reinterpret_cast<Acc*>(smem);
+    __shared__ HdbStage stage;
+    if (MODE == 1) hdb_stage_init(stage);
 
     const int qbase = a.q0 + blockIdx.y * QT;
     for (int i = threadIdx.x; i < QT * a.d; i += 256) {
@@ -175,9 +208,10 @@ __global__ __launch_bounds__(256) void hdb_scan_kernel(ScanArgs a, int nq_end) {
             const int64_t row = r0 + u_own;
             const int q = qbase + qt;
             if ((l16 & 3) == 0 && row < a.n && q < nq_end)
-                hdb_emit<MODE>(a, q, row, t * 16 + 4 * g + u_own, mine);
+                hdb_emit<MODE>(a, q, row, t * 16 + 4 * g + u_own, mine, MODE == 1 ? &stage : nullptr, qt);
         }
     }
+    if (MODE == 1) hdb_stage_flush(a, stage, (int)blockIdx.y * QT, min(QT, nq_end - qbase));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -188,6 +222,8 @@ __global__ __launch_bounds__(256) void hdb_scan_generic_kernel(ScanArgs a, int n
     using Acc = typename Elem<T>::Acc;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Acc* qs = reinterpret_cast<Acc*>(smem);
+    __shared__ HdbStage stage;
+    if (MODE == 1) hdb_stage_init(stage);
     const int q = a.q0 + blockIdx.y;
     for (int i = threadIdx.x; i < a.d; i += 256) qs[i] = reinterpret_cast<const Acc*>(a.Q)[(int64_t)q * a.d + i];
     __syncthreads();
@@ -211,8 +247,9 @@ __global__ __launch_bounds__(256) void hdb_scan_generic_kernel(ScanArgs a, int n
         const int u_own = hdb_owned_row(l16);
         const Acc mine = hdb_rows4_sum(acc[0], acc[1], acc[2], acc[3], l16);
         const int64_t row = r0 + u_own;
-        if ((l16 & 3) == 0 && row < a.n && q < nq_end) hdb_emit<MODE>(a, q, row, t * 16 + 4 * g + u_own, mine);
+        if ((l16 & 3) == 0 && row < a.n && q < nq_end) hdb_emit<MODE>(a, q, row, t * 16 + 4 * g + u_own, mine, MODE == 1 ? &stage : nullptr, 0);
     }
+    if (MODE == 1) hdb_stage_flush(a, stage, (int)blockIdx.y, q < nq_end ? 1 : 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -385,6 +422,8 @@ template <int MODE, bool JACCARD, int QH>
 __global__ __launch_bounds__(256) void hdb_hamming_kernel(ScanArgs a, const uint32_t* bits, int64_t npad, int W,
                                                           const uint32_t* qbits, int nq_end) {
     __shared__ uint32_t qb[QH][512];
+    __shared__ HdbStage stage;
+    if (MODE == 1) hdb_stage_init(stage);
     const int q0 = a.q0 + blockIdx.y * QH;
     for (int i = threadIdx.x; i < QH * W; i += 256) {
         const int qq = i / W, w = i - qq * W;
@@ -421,11 +460,12 @@ __global__ __launch_bounds__(256) void hdb_hamming_kernel(ScanArgs a, const uint
                 const int64_t row = 4 * i + u;
                 if (row < a.n && q < nq_end) {
                     const float sc = JACCARD ? (float)mism[qq][u] / (float)uni[qq][u] : (float)(a.d - (int)mism[qq][u]);
-                    hdb_emit<MODE>(a, q, row, 4 * j + u, sc);
+                    hdb_emit<MODE>(a, q, row, 4 * j + u, sc, MODE == 1 ? &stage : nullptr, qq);
                 }
             }
         }
     }
+    if (MODE == 1) hdb_stage_flush(a, stage, (int)blockIdx.y * QH, min(QH, nq_end - q0));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -487,6 +527,8 @@ extern "C" int hdb_launch_scan(const ScanArgs* args, int dtype, int mode, int nq
     // is the measured optimum (6.8 TB/s); with the 24 KiB tiles of the unrolled 1536-byte-row variant one workgroup
     // per CU is (N=1M fp32 d=384: 237 vs 246 us; N=10M: 7.02 vs 6.78 TB/s) -- the same ~100 KiB in flight per CU
     const bool wide_rows = vec && a.row_bytes == 6 * 256 && nq_launch < 2;      // (the one-query kernel; two or more queries take the four-query one)
+    // (several query groups, grid.y > 1: fewer blocks along x -- to cut the flush atomics, one per block and query -- was measured:
+    // n = 200k x 100 float32, 16 queries 143 -> 120 us, but 1M rows 418 -> 566 us: the groups drift apart and stop sharing V in L2)
     const int auto_blocks = wide_rows ? 256 : 512;
     const int blocks = hdb_grid_for(a.ntiles, 4, max_blocks > 0 ? max_blocks : auto_blocks);
     if (dtype == HDB_F16) { if (mode == 0) launch_scan_t<__half, 0>(a, nq_launch, blocks, vec, st); else launch_scan_t<__half, 1>(a, nq_launch, blocks, vec, st); }
