@@ -600,7 +600,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     need += align_up((size_t)nq * W * 4, 256);                               // qbits
     need += align_up((size_t)nq * ix->d * 2, 256);                           // fp16 queries (MFMA)
     need += align_up((size_t)nq * ix->d * 8, 256);                           // centred queries (pearson)
-    need += 2 * align_up((size_t)cq_max * 4, 256) + 256;                     // thr, cnt, tile counter
+    need += align_up((size_t)cq_max * 4, 256) + align_up((size_t)cq_max * 4 * HDB_CNT_STRIDE, 256) + 256;     // thr, cnt (a cache line per query), tile counter
     need += align_up((size_t)cq_max * 4 * HDB_RADIX_BINS * 4, 256);          // hist
     need += align_up((size_t)cq_max * 16, 256);                              // tie_info
     need += align_up((size_t)cq_max * HDB_CAND_CAP * 8, 256);                // cand
@@ -613,7 +613,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     uint32_t* qbits = b.take<uint32_t>((size_t)nq * W);
     void* q16 = b.take<uint16_t>((size_t)nq * ix->d);
     void* qc = b.take<double>((size_t)nq * ix->d);
-    float* thr = b.take<float>(cq_max); uint32_t* cnt = b.take<uint32_t>(cq_max);
+    float* thr = b.take<float>(cq_max); uint32_t* cnt = b.take<uint32_t>((size_t)cq_max * HDB_CNT_STRIDE);
     uint32_t* tile_ctr = b.take<uint32_t>(64);
     uint32_t* hist = b.take<uint32_t>((size_t)cq_max * 4 * HDB_RADIX_BINS);
     uint32_t* tie_info = b.take<uint32_t>((size_t)cq_max * 4);

@@ -105,6 +105,10 @@ __device__ __forceinline__ const uint4* hdb_bits_quad(const uint32_t* bits, int6
     return reinterpret_cast<const uint4*>(bits + (((i >> 6) * W + w) << 8) + 4 * (i & 63));
 }
 
+// Per-query candidate counters of the multi-kernel pipeline (ScanArgs::cnt): one per 128-byte cache line -- atomics to one line
+// serialize (~88 per us), and a 16-query filter pass on a small matrix flushes 512 blocks x 16 counters.  Index: cnt[q * HDB_CNT_STRIDE].
+#define HDB_CNT_STRIDE 32
+
 struct BitsArgs {
     const uint32_t* bits; int64_t npad; int32_t W;
     int64_t n; int32_t d;

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(512) void hdb_l1_tile_kernel(ScanArgs a, int nq_end
                         const unsigned int lp = atomicAdd(&scnt[slot], 1u);             // LDS
                         if (lp < (unsigned int)SCAP) sbuf[slot * SCAP + (int)lp] = ent;
                         else {
-                            const uint32_t pos = atomicAdd(&a.cnt[ql], 1u);
+                            const uint32_t pos = atomicAdd(&a.cnt[ql * HDB_CNT_STRIDE], 1u);
                             if (pos < a.cap) a.cand[(int64_t)ql * a.cap + pos] = ent;
                         }
                     }
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(512) void hdb_l1_tile_kernel(ScanArgs a, int nq_end
             const unsigned int have = scnt[slot] < (unsigned int)SCAP ? scnt[slot] : (unsigned int)SCAP;      // (block-uniform)
             if (have == 0u) continue;
             const int ql = qb0 - a.q0 + slot;
-            if (tid == 0) scnt[NG * NQH] = atomicAdd(&a.cnt[ql], have);
+            if (tid == 0) scnt[NG * NQH] = atomicAdd(&a.cnt[ql * HDB_CNT_STRIDE], have);
             __syncthreads();
             const unsigned int base = scnt[NG * NQH];
             for (unsigned int e = (unsigned int)tid; e < have; e += 512u)

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void hdb_rescore_euclid_kernel(unsigned long l
                                                                  const T* V, int d, const float* Q, const float* qsq, int q0,
                                                                  const float* bias) {
     const int ql = blockIdx.y, lane = threadIdx.x & 63;
-    const uint32_t n = cnt[ql] < cap ? cnt[ql] : cap;
+    const uint32_t n = cnt[ql * HDB_CNT_STRIDE] < cap ? cnt[ql * HDB_CNT_STRIDE] : cap;
     const float* qv = Q + (int64_t)(q0 + ql) * d;
     const float close2 = 0.05f * qsq[q0 + ql];
     for (uint32_t e = blockIdx.x * 4 + (threadIdx.x >> 6); e < n; e += gridDim.x * 4) {

@@ -366,7 +366,8 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
     int64_t ntiles = ONE ? f.s_tiles : a.ntiles;                // tiles of the current pass (MODE 2: the sample first)
     int64_t tstride = ONE ? f.s_stride : a.tile_stride;         // 1 = dense pass, > 1 = strided row sample
     uint32_t* const tile_ctr = ONE ? (a.tile_ctr ? f.ctl + HDB_BATCH_CTL_TILE : nullptr) : a.tile_ctr;   // MODE 2: a.tile_ctr != nullptr = "hand tiles out dynamically"
-    uint32_t* const gcnt = ONE ? f.ctl + HDB_BATCH_CTL_CNT : a.cnt;      // candidates appended per query
+    uint32_t* const gcnt = ONE ? f.ctl + HDB_BATCH_CTL_CNT : a.cnt;      // candidates appended per query ...
+    constexpr int GCS = ONE ? 1 : HDB_CNT_STRIDE;                       // ... at this stride (the multi-kernel pipeline keeps one counter per cache line)
     const int64_t gstep = gridDim.x;
 
     // Stage tile number t (global tile index) into ring slot st: waves 4-7 issue PPL LDS-DMA pieces of 1 KiB each
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
                 todo &= ~grp;
             }
             unsigned int base = 0u;
-            if (live && leader == lane) base = atomicAdd(&gcnt[qe], gsize);
+            if (live && leader == lane) base = atomicAdd(&gcnt[qe * GCS], gsize);
             base = (unsigned int)__shfl((int)base, leader, 64);
             const unsigned int pos = base + rank;
             if (live && pos < a.cap) a.cand[(int64_t)qe * a.cap + pos] = ent;
@@ -598,7 +599,7 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
                                         asm volatile("ds_write_b64 %0, %1\n\tds_write_b16 %2, %3"
                                                      :: "v"(seg_cb + (unsigned int)pos * 8u), "v"(ent), "v"(seg_cbq + (unsigned int)pos * 2u), "v"((unsigned int)ql) : "memory");
                                     } else {         // cannot happen while flushes keep 64 slots free; kept as a safety net
-                                        const unsigned int gpos = atomicAdd(&gcnt[ql], 1u);
+                                        const unsigned int gpos = atomicAdd(&gcnt[ql * GCS], 1u);
                                         if (gpos < a.cap) a.cand[(int64_t)ql * a.cap + gpos] = ent;
                                     }
                                 }
@@ -998,7 +999,7 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
         HDB_BSTAMP(8);
         unsigned long long* fbuf = reinterpret_cast<unsigned long long*>(smem);     // the ring is free now
         for (int q = (int)bidx; q < nq_all; q += (int)G) {
-            const uint32_t tot0 = __hip_atomic_load(gcnt + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t tot0 = __hip_atomic_load(gcnt + q * GCS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t tot = aborted ? 0u : tot0;
             const float ssq = xss[q];
             // euclidean scores come from ||v||^2 + ||q||^2 - 2 v.q, which cancels when v ~ q: candidates closer than 5 % of

@@ -55,7 +55,7 @@ __device__ __forceinline__ void hdb_stage_flush(const ScanArgs& a, HdbStage& st,
     for (int s = 0; s < nslots; ++s) {
         const unsigned int have = min(st.cnt[s], (unsigned int)HDB_STAGE_CAP);        // (block-uniform)
         if (have == 0u) continue;
-        if (threadIdx.x == 0) st.base = atomicAdd(&a.cnt[ql0 + s], have);
+        if (threadIdx.x == 0) st.base = atomicAdd(&a.cnt[(ql0 + s) * HDB_CNT_STRIDE], have);
         __syncthreads();
         const unsigned int base = st.base;
         for (unsigned int e = threadIdx.x; e < have; e += blockDim.x)
@@ -93,7 +93,7 @@ __device__ __forceinline__ void hdb_emit(const ScanArgs& a, int q, int64_t row, 
                 const unsigned int lp = atomicAdd(&stg->cnt[slot], 1u);              // LDS
                 if (lp < HDB_STAGE_CAP) { stg->buf[slot][lp] = ent; return; }
             }
-            const uint32_t pos = atomicAdd(&a.cnt[ql], 1u);                          // the slot is full: straight to the global list
+            const uint32_t pos = atomicAdd(&a.cnt[ql * HDB_CNT_STRIDE], 1u);         // the slot is full: straight to the global list
             if (pos < a.cap) a.cand[(int64_t)ql * a.cap + pos] = ent;
         }
     }

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64) void hdb_thr_kernel(const uint32_t* hist, int n
     const Prefix pf = hdb_derive_prefix(hist + (int64_t)q * 4 * HDB_RADIX_BINS, npass, m, lane);
     if (lane == 0) {
         thr[q] = (sample_n < m) ? -INFINITY : hdb_key2f(pf.key);
-        cnt[q] = 0;
+        cnt[q * HDB_CNT_STRIDE] = 0;
     }
 }
 
@@ -174,14 +174,14 @@ __global__ __launch_bounds__(1024) void hdb_sample_thr_kernel(const float* score
         }
         if (lane == 0) {
             thr[q] = (n < (int64_t)m || kth == 0u) ? -INFINITY : hdb_key2f(kth);
-            cnt[q] = 0;
+            cnt[q * HDB_CNT_STRIDE] = 0;
         }
     }
 }
 
 __global__ void hdb_fill_thr_kernel(float* thr, uint32_t* cnt, int nq, float v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nq) { thr[i] = v; cnt[i] = 0; }
+    if (i < nq) { thr[i] = v; cnt[i * HDB_CNT_STRIDE] = 0; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void hdb_collect_kernel(const float* scores, i
         const float s = sq[i];
         const uint32_t key = hdb_f2key(s);
         if (key > kth || (ties_all && key == kth)) {
-            const uint32_t pos = atomicAdd(&cnt[q], 1u);
+            const uint32_t pos = atomicAdd(&cnt[q * HDB_CNT_STRIDE], 1u);
             if (pos < cap) cand[(int64_t)q * cap + pos] = hdb_pack(s, (uint32_t)i);
         }
     }
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(1024) void hdb_ties_seq_kernel(const float* scores,
         __syncthreads();
         if (s_taken >= need) break;
     }
-    if (threadIdx.x == 0) cnt[q] = count_gt + need;       // > kth entries occupy [0, count_gt)
+    if (threadIdx.x == 0) cnt[q * HDB_CNT_STRIDE] = count_gt + need;       // > kth entries occupy [0, count_gt)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(1024) void hdb_finalize_kernel(const unsigned long 
                                                             int32_t* status, const int* qnan) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long buf[];
     const int q = blockIdx.x;
-    hdb_finalize_body(buf, cand + (int64_t)q * cap, cnt[q], q, cap, k, kk, row_base, idx_out, score_out, status,
+    hdb_finalize_body(buf, cand + (int64_t)q * cap, cnt[q * HDB_CNT_STRIDE], q, cap, k, kk, row_base, idx_out, score_out, status,
                       qnan ? qnan[q] : 0, 0);
 }
 
