@@ -133,6 +133,10 @@ struct hdb_index {
     int64_t use_mfma = 1;
     int64_t exact_bytes = (int64_t)1 << 30;
     int64_t bits_fused = 1;           // hamming / jaccard: try the sampled-threshold path first (exact path when it fails)
+    // knobs of the dispatch: -1 = the measured rule (tools/sweep_dispatch.py, profiles/r3_dispatch_few_queries.txt), else a fixed limit
+    int64_t fused_max_q = -1;         // hdb_mfma_fused_kernel takes calls of up to this many queries
+    int64_t f32_min_q = -1;           // float32 matrices: the matrix-core scan from this many queries on
+    int64_t bits_max_q = -1;          // hamming / jaccard: the single launch (four queries at a time) up to this many queries
     int64_t host_direct = 1;          // hdb_topk_host: kernels write a pinned host record themselves (no D2H copy)
     int64_t dyn_tiles = 1;            // MFMA filter pass: hand tiles out from a counter (0: static split)
     int64_t dyn_min_mb = 16;          // ... for passes of at least this many MiB of V per workgroup
@@ -355,6 +359,9 @@ extern "C" int hdb_set_option(hdb_index* ix, const char* name, int64_t value) {
     else if (!strcmp(name, "dyn_heavy")) ix->dyn_heavy = value;
     else if (!strcmp(name, "fused_timeout_us")) ix->fused_timeout_us = std::max<int64_t>(1, value);
     else if (!strcmp(name, "bits_fused")) ix->bits_fused = value;
+    else if (!strcmp(name, "fused_max_q")) ix->fused_max_q = value;
+    else if (!strcmp(name, "f32_min_q")) ix->f32_min_q = value;
+    else if (!strcmp(name, "bits_max_q")) ix->bits_max_q = value;
     else if (!strcmp(name, "profile")) { ix->profile = value; ix->ev_used = 0; }
     else return fail(HDB_ERR_ARG, std::string("hdb_set_option: unknown option ") + name);
     return HDB_OK;
@@ -403,6 +410,7 @@ static void prof_end(hdb_index* ix, hipStream_t st) {
 }
 
 static bool metric_ok(int metric) { return metric >= HDB_DOT && metric <= HDB_EUCLIDEAN_DIST; }
+#define HDB_FUSED_MAXQ_RULE 4
 static bool is_bits_metric(int metric) { return metric == HDB_HAMMING || metric == HDB_JACCARD; }
 
 static int ensure_pscale(hdb_index* ix, hipStream_t st) {
@@ -562,13 +570,24 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     // bound at 157 TFLOP/s) takes over where a second VALU pass would start
     // (rows that need K slices -- float32 d >= 1024, fp16 d >= 2048 -- likewise: up to 4 queries are one VALU pass at HBM speed, the
     // slices pay a second launch and the partial sums)
-    const int64_t min_q = (ix->dtype == HDB_F32 || hdb_mfma_ksplit_slices(ix->dtype, ix->d) > 0) ? std::max<int64_t>(ix->mfma_min_q, 5) : ix->mfma_min_q;
+    // float32: up to 4 queries are one VALU pass at HBM speed and the float32 matrix pipe binds early -- but three or four queries on
+    // rows of up to 384 elements are faster through the batched single launch from ~300k rows on (n = 2M x 384: 595 / 640 -> 510 us;
+    // d = 768: 1 030 vs 1 714, the VALU pass stays)
+    const int64_t f32_min_q = ix->f32_min_q >= 0 ? ix->f32_min_q : ((ix->d <= 384 && n >= 300000) ? 3 : 5);
+    const int64_t min_q = hdb_mfma_ksplit_slices(ix->dtype, ix->d) > 0 ? std::max<int64_t>(ix->mfma_min_q, 5)
+                        : ix->dtype == HDB_F32 ? std::max<int64_t>(ix->mfma_min_q, f32_min_q) : ix->mfma_min_q;
+    // hdb_mfma_fused_kernel is built around ONE multiplying wave and two selector waves: with 2-4 fp16 queries its sample phase and
+    // epilogue cost more than the batched single launch (eight multiplying waves) until the pass itself dominates -- n = 100k x 384,
+    // three queries: 124 vs 57 us; 500k: 128 vs 97; 1M: 162 vs 149; 2M: 267 vs 268; 5M: 591 vs 608 (four queries never win).
+    // float32 (VALU flavour, two queries): the single launch wins at every size.
+    const int64_t fused_max_q = ix->fused_max_q >= 0 ? ix->fused_max_q
+                              : ix->dtype == HDB_F32 ? HDB_FUSED_MAXQ_RULE : (n >= 1500000 ? 3 : 1);
     const bool mfma = ix->use_mfma && !is_ham && !small && nq >= min_q &&
                       hdb_mfma_supported(ix->dtype, ix->d, is_pearson ? (int)HDB_COSINE : metric);
     // 1-4 dot / cosine queries, k <= 128: one launch does everything (hdb_mfma_fused.h; fp16 on the matrix cores,
     // float32 in the VALU from the same staged tiles)
     const bool fused_shape = ix->use_fused && !exact && !small && k <= HDB_MAX_K && dev_status != nullptr && !is_ham &&
-                             hdb_mfma_fused_supported(ix->dtype, ix->d, metric, nq, kk) && (ix->dtype == HDB_F32 || mfma) &&
+                             hdb_mfma_fused_supported(ix->dtype, ix->d, metric, nq, kk) && (ix->dtype == HDB_F32 || mfma) && nq <= fused_max_q &&
                              // float32 d = 512 streams 32-KiB tiles (16 rows): below ~3 GB the five-kernel VALU pipeline is
                              // 2-5 % faster end to end (200 vs 210 us at 0.5 M rows, 376 vs 385 at 1 M; 728 vs 687 at 2 M)
                              !(ix->dtype == HDB_F32 && ix->d == 512 && n < 1500000) &&
@@ -629,7 +648,10 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     // for the six launches at N=10M, 78 vs 77 at 5M, 60 vs 63 at 1.25M, 44 vs 52 at 250k rows; four queries 135 vs 172 at N=10M --
     // profiles/r3_bits_variants.txt; bits_fused = 3 keeps one-query calls on 1M+ rows with the six launches, for comparison)
     const bool bits1_pre = ix->use_fused && ix->bits_fused && is_ham && !exact && !small && !full_sort && !f64 && dev_status != nullptr &&
-                           hdb_bits_fused_supported(metric, 1, W, kk) && (nq >= 2 || n < 1000000 || ix->bits_fused != 3);
+                           hdb_bits_fused_supported(metric, 1, W, kk) && (nq >= 2 || n < 1000000 || ix->bits_fused != 3) &&
+                           // (more than four queries: the six launches take them all in one go, grid.y = query groups -- 16 queries on
+                           // 100k rows 50 vs 148 us for four single launches in a row, 64 queries 67 vs 642; 10M rows 464 vs 524)
+                           nq <= (ix->bits_max_q >= 0 ? ix->bits_max_q : 4);
                            // (the single launch prepares its queries itself)
     if (!fused && !batch1 && !bits1_pre) LAUNCH_TRY(hdb_launch_qprep(dev_Q, nq, ix->d, f64, qinv, qsq, qnan, q16_in_prep ? q16 : nullptr, qscl, st));
     if (is_ham) {

@@ -1340,7 +1340,7 @@ def test_single_launch_pipeline_equals_multi_kernel_and_oracle(orc, n, d):
     Q = rng.standard_normal((4, d)).astype(np.float16).astype(np.float32)
     Q[1] = V[n // 3].astype(np.float32)
     Q[2] = rng.standard_normal(d).astype(np.float32) * 37.5          # a genuinely float32 query: norm sums must round alike in both pipelines
-    ix = GpuIndex(V)
+    ix = GpuIndex(V); ix.set_option("fused_max_q", 4)      # (by rule 2-4 fp16 queries reach this kernel from 1.5M rows on: forced here)
     try:
         bias = torch.rand(n, generator=torch.Generator().manual_seed(3)).float().cuda() * 0.2
         mask = (torch.rand(n, generator=torch.Generator().manual_seed(4)) < 0.3).to(torch.uint8).cuda()
@@ -1389,7 +1389,7 @@ def test_single_launch_pipeline_failure_paths(ranking, orc):
     base = rng.standard_normal((40, 384)).astype(np.float32).astype(np.float16)
     V = np.tile(base, (1500, 1))                           # 60k rows, every score repeated 1500 times
     q = rng.standard_normal(384).astype(np.float16).astype(np.float32)
-    ix = GpuIndex(V)
+    ix = GpuIndex(V); ix.set_option("fused_max_q", 4)      # (by rule 2-4 fp16 queries reach this kernel from 1.5M rows on: forced here)
     try:
         mid = METRIC_IDS["dot_product"]
         idx, sc = ix.topk(q.reshape(1, -1), 100, mid)      # overflow -> hdb_topk_host re-runs the exact path
@@ -1404,7 +1404,7 @@ def test_single_launch_pipeline_failure_paths(ranking, orc):
     # 700k rows = 43 tiles per workgroup: more than the parking area holds (a selector wave that serves two queries
     # gave up on the first only, the second kept its NaN threshold and wave 0 parked past the end of its buffer)
     V2 = torch.randn((700_000, 384), generator=torch.Generator(device="cuda").manual_seed(3), device="cuda").to(torch.float16)
-    ix = GpuIndex(V2)
+    ix = GpuIndex(V2); ix.set_option("fused_max_q", 4)      # (by rule 2-4 fp16 queries reach this kernel from 1.5M rows on: forced here)
     try:
         mid = METRIC_IDS["cosine_similarity"]
         for nq in (1, 2, 3, 4):
@@ -1440,7 +1440,7 @@ def test_single_launch_pipeline_threshold_minus_inf(dt, n, d, nq):
     g = torch.Generator(device="cuda").manual_seed(n + d)
     V = torch.randn((n, d), generator=g, device="cuda").to(torch.float16 if dt == np.float16 else torch.float32)
     Q = torch.randn((nq, d), generator=g, device="cuda").to(V.dtype).float()
-    ix = GpuIndex(V)
+    ix = GpuIndex(V); ix.set_option("fused_max_q", 4)      # (by rule 2-4 fp16 queries reach this kernel from 1.5M rows on: forced here)
     try:
         for keep in (0.05, 0.004):
             ix.set_row_mask((torch.rand(n, generator=g, device="cuda") < keep).to(torch.uint8))
@@ -1488,7 +1488,7 @@ def test_single_launch_pipeline_cluster_in_a_sample_tile(dt, n, d):
     noise = torch.randn((300, d), generator=g, device="cuda")
     mid = METRIC_IDS["cosine_similarity"]
     flagged = 0
-    ix = GpuIndex(V)
+    ix = GpuIndex(V); ix.set_option("fused_max_q", 4)      # (by rule 2-4 fp16 queries reach this kernel from 1.5M rows on: forced here)
     try:
         for trial in range(150):
             c0 = (trial * 9001 + 17) % (n - 300)
@@ -1533,7 +1533,7 @@ def test_single_launch_pipeline_winners_in_parked_tiles(orc, dt):
     scattered[rest] = V[order[128:][rng.permutation(n - 128)]]
     clean = 0
     for M in (scattered, np.ascontiguousarray(V[order])):
-        ix = GpuIndex(M)
+        ix = GpuIndex(M); ix.set_option("fused_max_q", 4)      # (by rule 2-4 fp16 queries reach this kernel from 1.5M rows on: forced here)
         try:
             for metric in ("dot_product", "cosine_similarity"):
                 mid = METRIC_IDS[metric]
@@ -1590,7 +1590,8 @@ def test_single_launch_pipeline_float32(orc, n, d):
                 idx, sc = ix.topk(Q[qi:qi + 1], 100, mid)
                 assert ix.stat("fused") == 1
                 orc.check_topk(idx[0], sc[0], V, Q[qi], metric, 100, tol=1e-5)
-        ix.topk_device(Q[:3], 10, METRIC_IDS["dot_product"]); assert ix.stat("fused") == 0      # three float32 queries: five-kernel pipeline
+        ix.topk_device(Q[:3], 10, METRIC_IDS["dot_product"])      # three float32 queries: the VALU five kernels; d <= 384 from 300k rows on: the batched launch
+        assert ix.stat("fused") == (2 if (d <= 384 and n >= 300_000) else 0)
         if not (d == 512 and n < 1_500_000):
             idx, sc = ix.topk(V[11:12].copy(), 3, METRIC_IDS["euclidean_metric"])                 # an exact duplicate of two stored rows
             assert ix.stat("fused") == 1 and idx[0][0] == 11 and idx[0][1] == n - 1 and sc[0][0] == 1.0 and sc[0][1] == 1.0
@@ -1735,7 +1736,7 @@ def test_bits_single_launch_equals_multi_kernel_and_exact(orc, dt, n, d):
     g = torch.Generator(device="cuda").manual_seed(n + d)
     V = torch.randn((n, d), generator=g, device="cuda").to(torch.float16 if dt == np.float16 else torch.float32)
     V[n - 1] = V[7]
-    ix = GpuIndex(V)
+    ix = GpuIndex(V); ix.set_option("bits_max_q", 16)      # (by rule more than four queries take the six launches in one go: forced here)
     try:
         bias = (torch.rand(n, generator=g, device="cuda") * 3.0).float()
         mask = (torch.rand(n, generator=g, device="cuda") < 0.3).to(torch.uint8)
@@ -1779,6 +1780,39 @@ def test_bits_single_launch_equals_multi_kernel_and_exact(orc, dt, n, d):
         assert ix.stat("fused") == 3 and (int(st[2].item()) & Q_NAN) and not (int(st[0].item()) & Q_NAN)
     finally:
         ix.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# 13a. which pipeline serves a call of a few queries (tools/sweep_dispatch.py, profiles/r3_dispatch_few_queries.txt)
+# ------------------------------------------------------------------------------------------------
+def test_dispatch_rules_for_few_queries(orc):
+    """One query: the 1-4-query single launch.  2-4 fp16 queries: the batched single launch below 1.5M rows (its eight multiplying
+    waves beat the one multiplying wave of the 1-4-query kernel until the pass dominates), the 1-4-query kernel above (2-3
+    queries).  float32, d <= 384, 3-4 queries: the batched launch from 300k rows on.  Hamming: up to four queries in one launch,
+    more through the six launches in one go.  Every choice returns the same rows."""
+    import torch
+    from hyperdb._native import GpuIndex, METRIC_IDS
+    g = torch.Generator(device="cuda").manual_seed(77)
+    cos, ham = METRIC_IDS["cosine_similarity"], METRIC_IDS["hamming_distance"]
+    for dt, n, expect in ((torch.float16, 200_000, {1: 1, 2: 2, 3: 2, 4: 2, 5: 2}), (torch.float16, 1_600_000, {1: 1, 2: 1, 3: 1, 4: 2, 5: 2}),
+                          (torch.float32, 100_000, {1: 1, 2: 1, 3: 0, 4: 0, 5: 2}), (torch.float32, 400_000, {1: 1, 2: 1, 3: 2, 4: 2, 5: 2})):
+        V = torch.randn((n, 384), generator=g, device="cuda").to(dt)
+        ix = GpuIndex(V)
+        try:
+            Q = torch.randn((8, 384), generator=g, device="cuda").to(dt).float()
+            for nq, kind in expect.items():
+                fi, fs, st = ix.topk_device(Q[:nq], 50, cos)
+                assert ix.stat("fused") == kind, (dt, n, nq)
+                ei, es, _ = ix.topk_device(Q[:nq], 50, cos, exact=True)
+                assert int(st.abs().sum().item()) != 0 or (torch.equal(fi, ei) and torch.equal(fs, es)), (dt, n, nq)
+            if dt == torch.float16:
+                for nq, kind in ((1, 3), (4, 3), (5, 0), (16, 0)):
+                    hi, hs = ix.topk(Q[:nq], 50, ham)
+                    assert ix.stat("fused") == kind, (n, nq)
+                    ei, es, _ = ix.topk_device(Q[:nq], 50, ham, exact=True)
+                    assert np.array_equal(hi, ei.cpu().numpy()) and np.array_equal(hs, es.cpu().numpy()), (n, nq)
+        finally:
+            ix.close()
 
 
 # ------------------------------------------------------------------------------------------------
