@@ -214,7 +214,7 @@ static int l1_launch(const ScanArgs& a, int mode, int nq_launch, int blocks, hip
 // One query: equal (the single-query scan keeps it).  fp16 d >= 640 keeps two float32 query copies per wave in 200+ registers and
 // spills: 3-5x slower than the scan, not dispatched.
 extern "C" int hdb_l1_tile_supported(int dtype, int d) {
-    if (dtype == HDB_F16) return d == 128 || d == 256 || d == 384;
+    if (dtype == HDB_F16) return d == 128 || d == 256 || d == 384 || d == 512 || d == 640 || d == 768;      // (512: two queries per wave; 640 / 768: one)
     if (dtype == HDB_F32) return d == 128 || d == 256 || d == 384;
     return 0;
 }
@@ -236,6 +236,9 @@ extern "C" int hdb_launch_l1_tile(const ScanArgs* args, int dtype, int mode, int
             case 128: return l1_launch<_Float16, 128, 64, 4>(a, mode, nq_launch, blocks, st);
             case 256: return l1_launch<_Float16, 256, 64, 4>(a, mode, nq_launch, blocks, st);
             case 384: return l1_launch<_Float16, 384, 64, 4>(a, mode, nq_launch, blocks, st);
+            case 512: return l1_launch<_Float16, 512, 32, 2>(a, mode, nq_launch, blocks, st);
+            case 640: return l1_launch<_Float16, 640, 32, 1>(a, mode, nq_launch, blocks, st);
+            case 768: return l1_launch<_Float16, 768, 32, 1>(a, mode, nq_launch, blocks, st);
             default: return (int)hipErrorNotSupported;
         }
     }
