@@ -211,8 +211,9 @@ static int l1_launch(const ScanArgs& a, int mode, int nq_launch, int blocks, hip
 // rows that are multiples of 256 bytes up to 1536 bytes (fp16 d <= 768, float32 d <= 384: two or four float32 queries per wave in registers)
 // Measured against the 4-query scan in one process (profiles/r3_manhattan_tile_vs_scan.txt): fp16 d=384, 5 M rows: 800 vs 1 372 us
 // (2 queries), 1 187 vs 2 558 (5), 1 390 vs 2 728 (8); fp16 d=128: 559 vs 986 (5); float32 d=384, 2 M rows: 594 vs 1 083 (5).
-// One query: equal (the single-query scan keeps it).  fp16 d >= 640 keeps two float32 query copies per wave in 200+ registers and
-// spills: 3-5x slower than the scan, not dispatched.
+// One query: equal (the single-query scan keeps it).  fp16 d = 512 keeps two queries per wave, d = 640 / 768 one (two copies of a
+// 768-element query are 96 registers next to the tile chunks: spills); they still share the staged tile between the waves:
+// d = 768, 2.5 M rows: 589 vs 1 231 us (2 queries), 1 531 vs 2 484 (5), 3 674 vs 4 813 (16); d = 512, 4 M rows: 1 275 vs 2 686 (5).
 extern "C" int hdb_l1_tile_supported(int dtype, int d) {
     if (dtype == HDB_F16) return d == 128 || d == 256 || d == 384 || d == 512 || d == 640 || d == 768;      // (512: two queries per wave; 640 / 768: one)
     if (dtype == HDB_F32) return d == 128 || d == 256 || d == 384;
