@@ -216,7 +216,7 @@ static int l1_launch(const ScanArgs& a, int mode, int nq_launch, int blocks, hip
 // d = 768, 2.5 M rows: 589 vs 1 231 us (2 queries), 1 531 vs 2 484 (5), 3 674 vs 4 813 (16); d = 512, 4 M rows: 1 275 vs 2 686 (5).
 extern "C" int hdb_l1_tile_supported(int dtype, int d) {
     if (dtype == HDB_F16) return d == 128 || d == 256 || d == 384 || d == 512 || d == 640 || d == 768;      // (512: two queries per wave; 640 / 768: one)
-    if (dtype == HDB_F32) return d == 128 || d == 256 || d == 384;
+    if (dtype == HDB_F32) return d == 128 || d == 256 || d == 384 || d == 512 || d == 768;      // (512: two queries per wave, 16-row tiles; 768: one)
     return 0;
 }
 
@@ -247,6 +247,8 @@ extern "C" int hdb_launch_l1_tile(const ScanArgs* args, int dtype, int mode, int
         case 128: return l1_launch<float, 128, 64, 4>(a, mode, nq_launch, blocks, st);
         case 256: return l1_launch<float, 256, 32, 4>(a, mode, nq_launch, blocks, st);
         case 384: return l1_launch<float, 384, 32, 2>(a, mode, nq_launch, blocks, st);      // (four queries spill three registers)
+        case 512: return l1_launch<float, 512, 16, 2>(a, mode, nq_launch, blocks, st);
+        case 768: return l1_launch<float, 768, 16, 1>(a, mode, nq_launch, blocks, st);
         default: return (int)hipErrorNotSupported;
     }
 }

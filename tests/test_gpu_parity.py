@@ -1911,7 +1911,8 @@ def test_wide_rows_k_slices_match_valu_scan_and_oracle(orc, dt, n, d, nq):
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dt,n,d", [(np.float16, 120_003, 384), (np.float16, 60_000, 256), (np.float16, 40_017, 128),
                                      (np.float32, 70_001, 384), (np.float32, 50_000, 128),
-                                     (np.float16, 50_001, 768), (np.float16, 40_000, 640), (np.float16, 60_003, 512)])
+                                     (np.float16, 50_001, 768), (np.float16, 40_000, 640), (np.float16, 60_003, 512),
+                                     (np.float32, 30_000, 768), (np.float32, 40_001, 512)])
 def test_manhattan_tile_kernel_matches_scan_and_oracle(orc, dt, n, d):
     """manhattan_distance for 1-20 queries per call: one pass over V with the queries in registers against the 4-query VALU
     scan (same rows; fp16 data subtracts in fp16 like the reference, so scores agree to fp16 rounding of the differences) and the

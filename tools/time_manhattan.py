@@ -6,7 +6,7 @@ import numpy as np, torch
 from hyperdb._native import GpuIndex, METRIC_IDS
 import bench
 dev = torch.device("cuda", 0)
-for dt, n, d in ((torch.float16, 5_000_000, 384), (torch.float16, 2_500_000, 768), (torch.float16, 3_000_000, 640), (torch.float16, 4_000_000, 512), (torch.float16, 5_000_000, 128), (torch.float32, 2_000_000, 384), (torch.float32, 4_000_000, 128)):
+for dt, n, d in ((torch.float16, 5_000_000, 384), (torch.float16, 2_500_000, 768), (torch.float16, 3_000_000, 640), (torch.float16, 4_000_000, 512), (torch.float16, 5_000_000, 128), (torch.float32, 2_000_000, 384), (torch.float32, 1_250_000, 768), (torch.float32, 2_000_000, 512), (torch.float32, 4_000_000, 128)):
     V, _, _ = bench.make_shard(n, d, dt, 0, 1, dev)
     ix = GpuIndex(V)
     es = 2 if dt == torch.float16 else 4
