@@ -599,7 +599,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     // <= bcap queries does preparation, sample, thresholds, the pass and every query's final sort (hdb_mfma_kernel.h, MODE 2)
     const int bcap = mfma ? hdb_mfma_batch_capacity(ix->dtype, ix->d) : 0;
     const bool batch1 = ix->use_fused && ix->use_batch1 && mfma && !fused_shape && !exact && !small && !full_sort && kk <= 128 &&
-                        dev_status != nullptr && !is_pearson && bcap > 0;
+                        dev_status != nullptr && bcap > 0;
 
     // ---- plan the chunking --------------------------------------------------------------------
     int64_t s_tiles = 0, s_stride = 1; uint32_t m = 0;
@@ -662,7 +662,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     int metric_eff = metric;
     if (is_pearson) {
         rc = ensure_pscale(ix, st); if (rc) return rc;
-        if (!fused) LAUNCH_TRY(hdb_launch_qcentre(dev_Q, nq, ix->d, f64, qc, qinv, st));     // qinv <- 1/sd_q (the single launch centres its queries itself)
+        if (!fused && !batch1) LAUNCH_TRY(hdb_launch_qcentre(dev_Q, nq, ix->d, f64, qc, qinv, st));     // qinv <- 1/sd_q (the single launches centre their queries themselves)
         Qeff = qc; metric_eff = HDB_COSINE;
     }
     if (full_sort) {
@@ -785,14 +785,15 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
         for (int q0 = 0; q0 < nq; q0 += cq_max) {
             const int cq = std::min(cq_max, nq - q0);
             ix->st_chunks++;
-            ScanArgs a; base_args(ix, a, dev_Q, metric);
+            ScanArgs a; base_args(ix, a, dev_Q, is_pearson ? (int)HDB_COSINE : metric);      // pearson: the cosine launch on queries the kernel centres, ...
+            if (is_pearson) a.inv_norm = ix->pscale;                                          // ... row scale 1/(sd_v d)
             a.bias = bias_eff; a.mask = nullptr; a.q0 = 0; a.nq = cq;
             a.ntiles = (n + tile_rows - 1) / tile_rows;
             a.cand = cand;
             a.tile_ctr = ix->dyn_tiles ? reinterpret_cast<uint32_t*>(ix->bctl) + HDB_BATCH_CTL_TILE : nullptr;
             BatchArgs fa; memset(&fa, 0, sizeof(fa));
             fa.Qraw = static_cast<const char*>(dev_Q) + (size_t)q0 * qrow;
-            fa.s_tiles = s_tiles; fa.s_stride = s_stride;
+            fa.s_tiles = s_tiles; fa.s_stride = s_stride; fa.centre = is_pearson ? 1 : 0;
             ix->fused_epoch = (ix->fused_epoch + 1) & 0x7FFFFFFFu;
             if (ix->fused_epoch == 0) ix->fused_epoch = 1;
             fa.epoch = ix->fused_epoch;

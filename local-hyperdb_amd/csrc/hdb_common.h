@@ -89,6 +89,7 @@ struct BatchArgs {
     uint32_t k, kk;
     int64_t row_base;
     int64_t* idx_out; float* score_out; int32_t* status;
+    int32_t centre;                 // pearson: the kernel centres its queries (hdb_qcentre_kernel) and multiplies by 1/sd_q; the launch is the cosine one, aux = 1/(sd_v d)
 };
 
 // Arguments of the single-launch top-k of the bit metrics (hdb_bits_fused.hip): 1-4 hamming / jaccard queries in one launch.

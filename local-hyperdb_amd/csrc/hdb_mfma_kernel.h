@@ -274,13 +274,14 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
         // butterfly), so 1/||q||, ||q||^2 and the NaN flag are bit-identical with the multi-kernel pipeline; the maximum
         // (the fp16 scale) does not depend on the order.  Lane (rl, h) keeps the values of query qt * MF + rl.
         const float* Qf = static_cast<const float*>(f.Qraw);
-        float ss_l[QT], amax_l[QT];
+        const bool centre = f.centre != 0;          // pearson: subtract the query's mean first, exactly as hdb_qcentre_kernel does (same partial sums, same tree)
+        float ss_l[QT], amax_l[QT], mean_l[QT];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
             const int q = qw0 + qt * MF + rl;
             q_ok[qt] = q < nq_end;
             ql[qt] = q - a.q0;
-            ss_l[qt] = 0.f; amax_l[qt] = 0.f;
+            ss_l[qt] = 0.f; amax_l[qt] = 0.f; mean_l[qt] = 0.f;
         }
         constexpr int QPL = (D + 63) / 64;
         constexpr int QB = QPW >= 32 ? 16 : 8;                // queries in flight per step
@@ -297,6 +298,17 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
                 }
 #pragma unroll
                 for (int j = 0; j < QB; ++j) {
+                    float mean = 0.f;
+                    if (centre) {
+                        float sm = 0.f;
+#pragma unroll
+                        for (int u = 0; u < QPL; ++u) sm += xs[j][u];
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+                        mean = sm / (float)D;
+#pragma unroll
+                        for (int u = 0; u < QPL; ++u) xs[j][u] = lane + 64 * u < D ? xs[j][u] - mean : 0.f;
+                    }
                     float ss = 0.f, am = 0.f;
 #pragma unroll
                     for (int u = 0; u < QPL; ++u) { ss = fmaf(xs[j][u], xs[j][u], ss); am = fmaxf(am, fabsf(xs[j][u])); }
@@ -305,7 +317,7 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
                     const int qi = qi0 + j;
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt)
-                        if (qi == qt * MF + rl) { ss_l[qt] = ss; amax_l[qt] = am; }
+                        if (qi == qt * MF + rl) { ss_l[qt] = ss; amax_l[qt] = am; mean_l[qt] = mean; }
                 }
             }
         }
@@ -320,14 +332,19 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
                 for (int s = 0; s < KS; ++s) {
                     if constexpr (ES == 2) {
                         const float4* src = reinterpret_cast<const float4*>(Qf + (int64_t)qq * D + (CPS * s + h) * 8);
-                        const float4 x0 = src[0], x1 = src[1];
+                        float4 x0 = src[0], x1 = src[1];
+                        if (centre) {
+                            const float mq = mean_l[qt];
+                            x0.x -= mq; x0.y -= mq; x0.z -= mq; x0.w -= mq; x1.x -= mq; x1.y -= mq; x1.z -= mq; x1.w -= mq;
+                        }
                         Vec v;
                         v[0] = (_Float16)(x0.x * scale); v[1] = (_Float16)(x0.y * scale); v[2] = (_Float16)(x0.z * scale); v[3] = (_Float16)(x0.w * scale);
                         v[4] = (_Float16)(x1.x * scale); v[5] = (_Float16)(x1.y * scale); v[6] = (_Float16)(x1.z * scale); v[7] = (_Float16)(x1.w * scale);
                         if (!q_ok[qt]) v = Vec{0, 0, 0, 0, 0, 0, 0, 0};
                         Bq[qt][s] = v;
                     } else {
-                        const float4 x0 = *reinterpret_cast<const float4*>(Qf + (int64_t)qq * D + (CPS * s + h) * 4);
+                        float4 x0 = *reinterpret_cast<const float4*>(Qf + (int64_t)qq * D + (CPS * s + h) * 4);
+                        if (centre) { const float mq = mean_l[qt]; x0.x -= mq; x0.y -= mq; x0.z -= mq; x0.w -= mq; }
                         Vec v = {x0.x, x0.y, x0.z, x0.w};
                         if (!q_ok[qt]) v = Vec{0.f, 0.f, 0.f, 0.f};
                         Bq[qt][s] = v;
@@ -341,7 +358,8 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
             if (q_ok[qt]) {
                 const float ss = ss_l[qt];
                 const float qs = 1.f / scale;                                      // a power of two: exact
-                const float qi = (ss == 0.f) ? 1.0f : 1.0f / sqrtf(ss);
+                float qi = (ss == 0.f) ? 1.0f : 1.0f / sqrtf(ss);
+                if (centre) { const float sd = sqrtf(ss / (float)D); qi = (sd == 0.f) ? __builtin_nanf("") : 1.0f / sd; }      // 1/sd_q, NaN for a constant query (:107-111)
                 qinv_l[qt] = METRIC == 1 ? qi * qs : qs;
                 if (METRIC == 2) qsq_l[qt] = ss;
                 if (h == 0) xss[ql[qt]] = ss;                                       // for the finish (NaN flag, euclidean re-score)

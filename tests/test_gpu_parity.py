@@ -1356,7 +1356,7 @@ def test_single_launch_pipeline_equals_multi_kernel_and_oracle(orc, n, d):
                     if metric == "euclidean_metric" and (d == 768 or nq > 1):
                         single = False                         # (d = 768: three registers short; 2-4 queries: the batched launch is faster)
                     # (what this kernel does not take goes to the batched single launch, stat 2: hdb_mfma_kernel.h MODE 2)
-                    other = 0 if metric == "pearson_correlation" else 2     # (pearson batches: the five kernels on the centred queries)
+                    other = 2                                               # (what this kernel does not take: the batched single launch)
                     assert ix.stat("fused") == (1 if single else other) and ix.stat("path") == 1 and int(fst.abs().sum().item()) == 0, (metric, setup, nq, k)
                     ix.set_option("use_fused", 0)
                     ui, us, ust = ix.topk_device(Q[:nq], k, mid)
@@ -1627,7 +1627,7 @@ def test_batched_single_launch_equals_multi_kernel_and_oracle(orc, dt, n, d, nqs
             Q[0] = V[n // 3].float()                       # an exact duplicate of a stored row (euclidean: re-scored directly)
             if nq > 2:
                 Q[2] = Q[2] * 37.5                         # a genuinely float32 query: norm sums must round alike in both pipelines
-            for metric in ("cosine_similarity", "dot_product", "euclidean_metric"):
+            for metric in ("cosine_similarity", "dot_product", "euclidean_metric", "pearson_correlation"):     # (pearson: the kernel centres its queries)
                 if metric != "euclidean_metric" and nq <= (4 if d <= 768 else 2) and dt == np.float16:
                     continue                               # hdb_mfma_fused_kernel's calls
                 if dt == np.float32 and nq < 5:

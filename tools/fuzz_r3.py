@@ -28,7 +28,7 @@ for case in range(cases):
         nq = int(rng.integers(1, 8))
     elif family == "batch":
         d = int(rng.choice([128, 256, 384, 512, 768, 1024, 1536])) if f16 else int(rng.choice([128, 256, 384, 512, 768]))
-        metric = str(rng.choice(["dot_product", "cosine_similarity", "euclidean_metric"]))
+        metric = str(rng.choice(["dot_product", "cosine_similarity", "euclidean_metric", "pearson_correlation"]))
         nq = int(rng.choice([5, 8, 16, 33, 64, 100, 130, 256, 300]))
     else:
         d = int(rng.choice([256, 384, 512, 640, 768, 1024, 1152, 1280, 1408, 1536])) if f16 else int(rng.choice([128, 256, 384, 512, 768]))
