@@ -225,8 +225,13 @@ void hdb_group_destroy(hdb_group* g);
  *   host_poll (0: hdb_topk_host always waits on the stream instead of polling the status words of a pinned record),
  *   dyn_tiles (0: the batched MFMA filter pass always splits its tiles statically; default 1 = tiles from a counter for
  *   long passes over rows of >= 768 bytes with up to 64 queries).
+ *   Dispatch of few-query calls (-1 = the measured rule): fused_max_q (the 1-4-query single launch takes
+ *   calls of up to this many queries), f32_min_q (float32 matrices: the matrix-core scan from this many queries on), bits_max_q
+ *   (hamming / jaccard: single launches of four queries up to this many queries, more through the six launches in one go);
+ *   use_batch1 (0: never the batched single launch), use_l1_tile (0: manhattan batches stay with the 4-query scan).
  *   max_blocks < 0 asks for -max_blocks workgroups per CU in the batched MFMA scan (measured: no gain).
- * Stats:    path (0 small, 1 sampled threshold, 2 exact, 3 full sort), mfma, fused, host_direct, chunks, sample_rows, sample_m,
+ * Stats:    path (0 small, 1 sampled threshold, 2 exact, 3 full sort), mfma, fused (0 multi-kernel, 1 the 1-4-query single launch,
+ *   2 the batched single launch, 3 the bit-metric single launch), host_direct, chunks, sample_rows, sample_m,
  *   scan_launches, scan_time_ns (sum over the profiled launches), cand_cap, n, ws_bytes. */
 int hdb_set_option(hdb_index* ix, const char* name, int64_t value);
 int hdb_get_stat(hdb_index* ix, const char* name, int64_t* value);
