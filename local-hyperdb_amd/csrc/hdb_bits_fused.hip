@@ -15,7 +15,8 @@
 //             the 8-th largest -- a lower bound of the 8-th largest sample score, which is all a threshold needs -- and
 //             publishes it as one {epoch, key} word; every workgroup polls the nq words;
 //   filter    the pass over all sign bits, handed out in two levels (1024-quad chunks from a global counter, 64-quad pieces from
-//             an LDS word) and begun before the threshold is there; rows at or above it go to the per-query candidate lists;
+//             an LDS word) and begun before the threshold is there; rows at or above it wait in LDS (the final sort's buffers are
+//             idle until then) and go to the per-query candidate lists with one atomic per query at the end;
 //   finish    drain, agent-scope release, arrive; when every workgroup has arrived, the owner of each query sorts its list
 //             (hdb_finalize_body) and writes the k results and the status word; the last workgroup out zeroes the counters.
 // Scores are small integers (hamming) with massive ties: everything at the threshold's own level survives, the sample plan aims
