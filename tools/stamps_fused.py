@@ -27,7 +27,8 @@ def run():
     dev = torch.device('cuda', 0)
     lib = _native.lib()
     lib.hdb_debug_read_fused_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
-    for (n, dt) in ((1_250_000, torch.float16), (10_000_000, torch.float16), (1_000_000, torch.float32)):
+    sizes = [(int(x), torch.float16) for x in sys.argv[2:]] or [(1_250_000, torch.float16), (10_000_000, torch.float16), (1_000_000, torch.float32)]
+    for (n, dt) in sizes:
       V, lo, hi = bench.make_shard(n, 384, dt, 0, 1, dev)
       for unc in (0,):
         ix = GpuIndex(V)
