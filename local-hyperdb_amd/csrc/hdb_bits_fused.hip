@@ -95,7 +95,7 @@ __device__ __forceinline__ uint32_t hdb_wg_top8(uint32_t a, uint32_t b, uint32_t
     return out;
 }
 
-template <bool JACCARD, int QH>
+template <bool JACCARD, int QH, bool NT>
 __global__ __launch_bounds__(HDB_BITS_THREADS) void hdb_bits_fused_kernel(BitsArgs a) {
     static_assert(HDB_BITS_WAVES == 16 || HDB_BITS_WAVES == 8, "hdb_wg_top8 reads 64 or 128 keys");
     extern __shared__ __attribute__((aligned(16))) unsigned long long fbuf[];       // hdb_finalize_body's buffers first ...
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(HDB_BITS_THREADS) void hdb_bits_fused_kernel(BitsAr
             uint4 v[CW];
 #pragma unroll
             for (int c = 0; c < CW; ++c)
-                v[c] = (w0 + c < W) ? *hdb_bits_quad(a.bits, i, w0 + c, W) : make_uint4(0, 0, 0, 0);
+                v[c] = (w0 + c < W) ? hdb_bits_load<NT>(a.bits, i, w0 + c, W) : make_uint4(0, 0, 0, 0);
 #pragma unroll
             for (int c = 0; c < CW; ++c) {
                 const uint32_t vv[4] = {v[c].x, v[c].y, v[c].z, v[c].w};
@@ -452,11 +452,12 @@ extern "C" int hdb_launch_bits_fused(const BitsArgs* args, int jaccard, int max_
     if ((int64_t)blocks * HDB_BITS_THREADS > items) blocks = (int)((items + HDB_BITS_THREADS - 1) / HDB_BITS_THREADS);
     if (max_blocks > 0 && max_blocks < blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
+    const bool nt = (size_t)a.npad * a.W * 4 > ((size_t)256 << 20);      // the sign bits do not fit the Infinity Cache: stream them past it (5M x 384 = 240 MB still gain from it)
 #define HDB_BITS_LAUNCH(JAC_, QH_)                                                                                          \
     do {                                                                                                                    \
-        auto kern = hdb_bits_fused_kernel<JAC_, QH_>;                                                                       \
-        static unsigned long long attr_done = 0;                                                                            \
-        hipError_t e = hdb_lds_attr_once(reinterpret_cast<const void*>(kern), (int)lds, &attr_done);                        \
+        auto kern = nt ? hdb_bits_fused_kernel<JAC_, QH_, true> : hdb_bits_fused_kernel<JAC_, QH_, false>;                  \
+        static unsigned long long attr_done[2] = {0, 0};                                                                    \
+        hipError_t e = hdb_lds_attr_once(reinterpret_cast<const void*>(kern), (int)lds, &attr_done[nt ? 1 : 0]);            \
         if (e != hipSuccess) return (int)e;                                                                                 \
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(HDB_BITS_THREADS), lds, st, a);                                         \
     } while (0)

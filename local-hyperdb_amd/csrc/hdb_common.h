@@ -105,6 +105,15 @@ __host__ __device__ __forceinline__ int64_t hdb_bits_word(int64_t row, int w, in
 __device__ __forceinline__ const uint4* hdb_bits_quad(const uint32_t* bits, int64_t i, int w, int W) {
     return reinterpret_cast<const uint4*>(bits + (((i >> 6) * W + w) << 8) + 4 * (i & 63));
 }
+// ... loaded once per pass.  NT: non-temporal -- 3-4 % faster when the bits do not fit the 256 MB Infinity Cache (N = 10M x 384: 114 vs 119 us
+// per call), 2-3 % slower when they do and a query stream keeps finding them there (5M rows: 75 vs 73 us; profiles/r3_bits_variants.txt)
+typedef unsigned int hdb_u32x4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ uint4 hdb_bits_load(const uint32_t* bits, int64_t i, int w, int W) {
+    const hdb_u32x4* p = reinterpret_cast<const hdb_u32x4*>(bits + (((i >> 6) * W + w) << 8) + 4 * (i & 63));
+    const hdb_u32x4 v = NT ? __builtin_nontemporal_load(p) : *p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 
 // Per-query candidate counters of the multi-kernel pipeline (ScanArgs::cnt): one per 128-byte cache line -- atomics to one line
 // serialize (~88 per us), and a 16-query filter pass on a small matrix flushes 512 blocks x 16 counters.  Index: cnt[q * HDB_CNT_STRIDE].

@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256) void hdb_hamming_kernel(ScanArgs a, const uint
 #pragma unroll
             for (int u = 0; u < 4; ++u) { mism[qq][u] = 0; uni[qq][u] = 0; }
         for (int w = 0; w < W; ++w) {
-            const uint4 v = *hdb_bits_quad(bits, i, w, W);
+            const uint4 v = hdb_bits_load<false>(bits, i, w, W);
             const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int qq = 0; qq < QH; ++qq) {

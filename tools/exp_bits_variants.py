@@ -7,8 +7,8 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'local-hyperdb_amd', 'csrc')
 OUT = os.path.join(ROOT, 'local-hyperdb_amd', 'lib', 'bitsvar')
-# name: (threads per workgroup, tail chunks on/off, chunk / tail chunk, tail share in %, prefetch point, poll: 0 = sc1 loads, 1 = returning atomics)
-VARIANTS = {'poll_load': (1024, 1, 4, 15, 1, 0), 'poll_atomic': (1024, 1, 4, 15, 1, 1)}
+# name: (threads per workgroup, tail chunks on/off, chunk / tail chunk, tail share in %, prefetch point, poll, non-temporal loads of the sign bits)
+VARIANTS = {'nt_loads': (1024, 1, 4, 15, 1, 0, 1), 'plain_loads': (1024, 1, 4, 15, 1, 0, 0)}
 CHILD = r'''
 import sys, time, json
 sys.path.insert(0, 'local-hyperdb_amd'); sys.path.insert(0, '.')
@@ -17,7 +17,7 @@ from hyperdb._native import GpuIndex, METRIC_IDS
 import bench
 dev = torch.device('cuda', 0)
 out = {}
-for n in (10_000_000, 2_500_000, 1_250_000, 250_000):
+for n in (10_000_000, 5_000_000, 1_250_000):
     V, lo, hi = bench.make_shard(n, 384, torch.float16, 0, 1, dev)
     ix = GpuIndex(V)
     mid = METRIC_IDS['hamming_distance']
@@ -39,10 +39,10 @@ def build():
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     objs = [os.path.join(CSRC, 'obj', f) for f in sorted(os.listdir(os.path.join(CSRC, 'obj'))) if f.endswith('.o') and f != 'hdb_bits_fused.o']
     procs = []
-    for name, (thr, tail, tdiv, tpct, pref, poll) in VARIANTS.items():
+    for name, (thr, tail, tdiv, tpct, pref, poll, nt) in VARIANTS.items():
         o = os.path.join(OUT, name + '.o')
         procs.append(subprocess.Popen([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-pass-failed', f'-DHDB_BITS_THREADS={thr}',
-                                       f'-DHDB_BITS_TAIL={tail}', f'-DHDB_BITS_TAILDIV={tdiv}', f'-DHDB_BITS_TAILPCT={tpct}', f'-DHDB_BITS_PREF={pref}', f'-DHDB_BITS_POLL={poll}',
+                                       f'-DHDB_BITS_TAIL={tail}', f'-DHDB_BITS_TAILDIV={tdiv}', f'-DHDB_BITS_TAILPCT={tpct}', f'-DHDB_BITS_PREF={pref}', f'-DHDB_BITS_POLL={poll}', f'-DHDB_BITS_NT={nt}',
                                        '-c', os.path.join(CSRC, 'hdb_bits_fused.hip'), '-o', o]))
     for p in procs:
         if p.wait(): raise SystemExit('hipcc failed')
