@@ -30,6 +30,14 @@ One JSON line is printed by rank 0.  Besides the contract fields it carries
                    ranking_algorithm.py:149, hyperdb.py:1584), beside the p50 of the kernel path the headline times.
   exchange_alt  -- (--gpus N > 1) both transports of the per-query exchange are timed in the same run: `value` uses the one
                    named in config.exchange (chosen by a calibration inside the warm-up), exchange_alt reports the other.
+  extra         -- (--gpus 1, default legs c2,c5,hamming,shard,small) the other BASELINE.json configs and the supplementary
+                   workloads, each with workload / kernel / kernel_us / roofline{achieved, peak, frac, algorithmic_bytes_per_launch}:
+                   c2 = config 2 (N=1M fp32 cosine), c5 = config 5 (N=10M d=768 euclidean + time decay, Q=64), hamming = the
+                   headline matrix through hamming_distance, shard = the per-GPU share of the headline at 8 GPUs (N=1.25M),
+                   small = p50 of the drop-in entry point on reference-sized matrices (1k / 10k / 100k rows, host numpy queries).
+  rccl          -- (--gpus N > 1) {backend, world, devices: [(rank, host, local device, pci bus id) all-gathered from the ranks],
+                   exchange, record_bytes} and `parity`: the sharded answer on a 1M-row prefix of the same matrix against rank 0's
+                   single-index answer (identical: bool, crc32 of the index lists) -- N ranks on N devices and index parity in one line.
 """
 import argparse
 import json
@@ -68,7 +76,8 @@ def parse():
     ap.add_argument("--batch-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=1_000_000, help="row prefix the CPU baseline is timed on (BASELINE.md section 4)")
-    ap.add_argument("--extra", default="", help="comma list of extra BASELINE configs to time after the headline: c2,c5")
+    ap.add_argument("--extra", default="c2,c5,hamming,shard,small",
+                    help="comma list of extra legs timed after the headline (one GPU): c2,c5,hamming,shard,small; '' = none")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run")
     return ap.parse_args()
@@ -150,6 +159,10 @@ def extra_leg(name, device):
         n, d, dt, elem, q, metric, steps, bias = 10_000_000, 768, torch.float16, 2, 64, "euclidean_metric", 10, True
     elif name == "hamming":   # supplementary: the headline matrix through hamming_distance
         n, d, dt, elem, q, metric, steps, bias = 10_000_000, 384, torch.float16, 2, 1, "hamming_distance", 200, False
+    elif name == "shard":     # what one GPU of an 8-GPU node holds of the headline matrix (strong scaling): the call that bounds the 8-GPU QPS
+        n, d, dt, elem, q, metric, steps, bias = 1_250_000, 384, torch.float16, 2, 1, "cosine_similarity", 300, False
+    elif name == "small":
+        return small_leg(device)
     else:
         raise SystemExit(f"unknown extra config {name}")
     V, lo, hi = make_shard(n, d, dt, 0, 1, device)
@@ -177,15 +190,88 @@ def extra_leg(name, device):
     alg = n * d * elem
     if metric == "hamming_distance":
         alg = n * ((d + 31) // 32) * 4              # packed sign bits, word-major: what the scan reads (one-time pack excluded)
+    fused = ix.stat("fused")
+    kernel = {1: "hdb_mfma_fused_kernel", 2: "hdb_mfma_kernel MODE 2", 3: "hdb_bits_fused_kernel"}.get(fused, "hdb_mfma_kernel / hdb_scan_kernel filter pass")
     out = {"config": name, "workload": f"N={n} d={d} {'fp32' if elem == 4 else 'fp16'} Q={q} {metric}{' + recency bias' if bias else ''} top-100",
            "qps": q * steps / el, "ms_per_call": 1e3 * el / steps, "p50_ms": 1e3 * float(np.median(lat)),
-           "kernel_us": kern_s * 1e6, "mfma_path": bool(ix.stat("mfma")), "single_launch": bool(ix.stat("fused")),
+           "kernel": kernel + (" (single launch: the whole call)" if fused else ""), "launches_timed": nl,
+           "kernel_us": kern_s * 1e6, "mfma_path": bool(ix.stat("mfma")), "single_launch": bool(fused),
            "roofline": {"bound": "hbm", "achieved": alg / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": alg / kern_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg}}
     ix.close()
     del V
     torch.cuda.empty_cache()
     return out
+
+
+def small_leg(device):
+    """Reference-sized matrices (the reference's perf test uses 10 000 documents, its demo 151: tests/perf_hyperdb.py:15): p50 of
+    hyperDB_ranking_algorithm_sort(handle, q_numpy, top_k=100) -- the drop-in entry point, host query in, host result out."""
+    import hyperdb.ranking_algorithm as ranking
+    rows = []
+    for dt, npdt in ((torch.float16, np.float16), (torch.float32, np.float32)):
+        for n in (1_000, 10_000, 100_000):
+            V, _, _ = make_shard(n, 384, dt, 0, 1, device)
+            h = ranking.register_vectors(V)
+            qs = make_queries(32, 384, dt, device).cpu().numpy().astype(npdt)
+            for metric in ("cosine_similarity", "hamming_distance"):
+                for i in range(10):
+                    ranking.hyperDB_ranking_algorithm_sort(h, qs[i].copy(), top_k=100, metric=metric)
+                t = np.empty(200)
+                for i in range(200):
+                    q = qs[i % 32].copy()
+                    t0 = time.perf_counter()
+                    ranking.hyperDB_ranking_algorithm_sort(h, q, top_k=100, metric=metric)
+                    t[i] = time.perf_counter() - t0
+                rows.append({"rows": n, "dtype": "fp16" if dt == torch.float16 else "fp32", "metric": metric,
+                             "p50_us": 1e6 * float(np.median(t)), "p99_us": 1e6 * float(np.percentile(t, 99)),
+                             "single_launch": h.index.stat("fused"), "local_flavour": bool(h.index.stat("local"))})
+            h.close()
+            del V
+    torch.cuda.empty_cache()
+    return {"config": "small", "workload": "d=384 Q=1 top-100 through hyperDB_ranking_algorithm_sort(handle, q_numpy), host to host",
+            "p50_by_rows": rows}
+
+
+def rccl_block(args, dist, rank, world, device, sharded_kind, tdtype, mid):
+    """N > 1: which ranks sat on which devices (all-gathered), what the exchange moved, and index parity of the sharded path against
+    rank 0's single index on a 1M-row prefix of the same matrix (block seeds make the prefix identical for every GPU count)."""
+    import socket
+    import zlib
+    from hyperdb._native import GpuIndex, packed_bytes
+    from hyperdb.sharded import ShardedIndex
+    props = torch.cuda.get_device_properties(device)
+    mine = {"rank": rank, "host": socket.gethostname(), "device": device.index,
+            "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", "")) or None}
+    devs = [None] * world
+    dist.all_gather_object(devs, mine)
+    n_pre = min(1_000_000, args.n)
+    Vp, plo, phi = make_shard(n_pre, args.d, tdtype, rank, world, device)
+    loc = GpuIndex(Vp, device=device, row_base=plo)
+    sh = ShardedIndex(loc, n_total=n_pre, group=dist.group.WORLD, exchange="host" if "shared-memory" in sharded_kind else "collective")
+    Qp = make_queries(8, args.d, tdtype, device).to(torch.float32)
+    got_i, got_s = sh.query(Qp, args.k, mid)
+    ident, crc = None, zlib.crc32(np.ascontiguousarray(got_i).tobytes())
+    if rank == 0:                                           # (no collective in here: a failure must not leave the other ranks waiting)
+        try:
+            Vw, _, _ = make_shard(n_pre, args.d, tdtype, 0, 1, device)
+            whole = GpuIndex(Vw, device=device)
+            wi, ws = whole.topk(Qp, args.k, mid)
+            ident = bool(np.array_equal(wi, got_i) and np.array_equal(ws, got_s))
+            whole.close()
+            del Vw
+        except Exception as e:                               # noqa: BLE001
+            ident = f"not checked: {e!r}"[:200]
+    crcs = [None] * world
+    dist.all_gather_object(crcs, crc)
+    sh.close(); loc.close()
+    del Vp
+    torch.cuda.empty_cache()
+    return {"backend": str(dist.get_backend()), "world": world, "devices": devs,
+            "distinct_devices": len({(d_["host"], d_["pci_bus_id"] or d_["device"]) for d_ in devs}),
+            "exchange": sharded_kind, "record_bytes": int(packed_bytes(1, args.k)),
+            "parity": {"rows": n_pre, "queries": 8, "top_k": args.k, "sharded_equals_single_index_on_rank0": ident,
+                       "index_crc32_per_rank": crcs, "ranks_agree": len(set(crcs)) == 1}}
 
 
 def main():
@@ -352,6 +438,13 @@ def main():
             traffic = None
 
     exchange_desc = kind_of(sharded)
+    rccl = None
+    if dist and world > 1:
+        barrier()
+        try:
+            rccl = rccl_block(args, dist, rank, world, device, exchange_desc, tdtype, mid)
+        except Exception as e:                                   # noqa: BLE001 -- a diagnostics block must not take the line down
+            rccl = {"error": repr(e)[:300]}
     exchange_alt = None
     if alt is not None:
         barrier()
@@ -437,6 +530,8 @@ def main():
         }
         if exchange_alt is not None:
             out["exchange_alt"] = exchange_alt
+        if rccl is not None:
+            out["rccl"] = rccl
         if extras:
             out["extra"] = extras
         print(json.dumps(out))

@@ -211,7 +211,12 @@ void hdb_group_destroy(hdb_group* g);
 
 /* Largest k served by the selection kernels.  hdb_topk / hdb_topk_exact accept any k: above HDB_MAX_K (on a
  * matrix of more than 8192 rows) they materialise the scores of each query and radix-sort them (cold path,
- * "top_k > N returns all rows sorted", ranking_algorithm.py:195-200).  hdb_merge_topk* need parts*k <= 8192. */
+ * "top_k > N returns all rows sorted", ranking_algorithm.py:195-200).
+ * The two DEVICE merges, hdb_merge_topk and hdb_merge_topk_packed, rank parts*k entries per query in LDS and return
+ * HDB_ERR_UNSUPPORTED beyond parts*k = 8192 (8 ranks: k > 1024).  Nothing above the C ABI is limited by that:
+ * hdb_merge_topk_host, hdb_host_exchange_merge and hdb_group_topk_host merge on the host with any parts*k, and the
+ * one-process-per-GPU path (hyperdb/sharded.py) copies the all-gathered records to the host and calls
+ * hdb_merge_topk_host whenever parts*k exceeds the cap, with either exchange transport. */
 #define HDB_MAX_K 2048
 
 /* Tuning knobs / introspection (bench and tests): name -> value, returns HDB_ERR_ARG if unknown.

@@ -60,6 +60,7 @@ size_t hdb_mfma_batch_ctl_bytes(int wgs);
 int hdb_mfma_fused_supported(int dtype, int d, int metric, int nq, uint32_t kk);
 size_t hdb_mfma_fused_ctl_bytes(void);
 int hdb_launch_mfma_fused(const ScanArgs* args, int dtype, const FusedArgs* fa, int max_blocks, void* stream);
+int hdb_mfma_fused_local_tiles(int dtype, int d, int metric, int nq);
 int hdb_launch_q_to_f16(const float* Q, int nq, int d, void* q16, float* qscl, void* stream);
 int hdb_sort_temp_bytes(int64_t n, size_t* bytes);
 int hdb_launch_full_sort(const float* scores, int64_t n, int64_t k, int64_t row_base, uint32_t* work, void* temp, size_t temp_bytes,
@@ -133,6 +134,7 @@ struct hdb_index {
     int64_t use_mfma = 1;
     int64_t exact_bytes = (int64_t)1 << 30;
     int64_t bits_fused = 1;           // hamming / jaccard: try the sampled-threshold path first (exact path when it fails)
+    int64_t bits_local = 1;           // ... its single launch without row sample and exchange: every workgroup its own threshold (hdb_bits_fused.hip, round 4)
     // knobs of the dispatch: -1 = the measured rule (tools/sweep_dispatch.py, profiles/r3_dispatch_few_queries.txt), else a fixed limit
     int64_t fused_max_q = -1;         // hdb_mfma_fused_kernel takes calls of up to this many queries
     int64_t f32_min_q = -1;           // float32 matrices: the matrix-core scan from this many queries on
@@ -143,13 +145,21 @@ struct hdb_index {
     int64_t dyn_heavy = 0;            // ... also when all eight waves multiply (measured: 1.3-5 % slower at 256 queries, profiles/r3_q256_clock.json)
     int64_t host_poll = 1;            // hdb_topk_host + single-launch pipeline + pinned record: poll the status words instead of the stream
     int64_t use_fused = 1;            // 1-4 dot / cosine queries on an fp16 matrix: the whole call in ONE kernel (hdb_mfma_fused.h)
+    int64_t use_local = 1;            // ... short matrices: its local flavour (no row sample, no exchange; every workgroup its own threshold)
+    int64_t local_m = 0;              // ... rows every workgroup emits at least (0 = automatic: ~3072 / workgroups, 8 .. 32)
+    int64_t local_max_q = 2;          // ... for calls of up to this many queries (three and four: the batched single launch is faster, profiles/r4_latency_map.txt)
     int64_t use_l1_tile = 1;          // manhattan: dense passes through the LDS-staged tile kernel (hdb_l1_tile.hip)
     int64_t use_batch1 = 1;           // 5+ queries (euclidean: 1+) on the matrix cores, k <= 128: the whole call in ONE launch per <= 256 queries (needs use_fused)
     int64_t fused_timeout_us = 2000;  // bound of every in-kernel spin of those kernels
     int64_t finalize_threads = 1024;  // workgroup size of hdb_finalize_kernel (256 | 512 | 1024)
     int64_t mfma_variant = 16;        // MFMA shape of the d=384 256-query pass (16 | 32)
     // stats of the last hdb_topk call
-    int64_t st_sample_rows = 0, st_sample_m = 0, st_path = 0, st_chunks = 0, st_mfma = 0, st_host_direct = 0, st_fused = 0;
+    int64_t st_sample_rows = 0, st_sample_m = 0, st_path = 0, st_chunks = 0, st_mfma = 0, st_host_direct = 0, st_fused = 0, st_local = 0;
+    // host-side timing of hdb_topk_host (always on: four clock reads per call), cumulative since "host_timing_reset":
+    // entry -> launch, the launch call itself, launch -> record complete (poll / stream wait), calls
+    int64_t ht_pre_ns = 0, ht_launch_ns = 0, ht_wait_ns = 0, ht_calls = 0;
+    std::chrono::steady_clock::time_point ht_l0, ht_l1;     // around the launch of the single-launch pipelines (topk_impl)
+    int64_t ht_attr_ns = 0;            // ... of which hipSetDevice + hipPointerGetAttributes (is the caller's record pinned?)
     // optional HIP-event timing of the dominant kernel (the pass over all of V)
     int64_t profile = 0;
     std::vector<hipEvent_t> ev_pool;      // pairs: [2i] start, [2i+1] stop
@@ -352,6 +362,9 @@ extern "C" int hdb_set_option(hdb_index* ix, const char* name, int64_t value) {
     else if (!strcmp(name, "host_direct")) ix->host_direct = value;
     else if (!strcmp(name, "use_fused")) ix->use_fused = value;
     else if (!strcmp(name, "use_batch1")) ix->use_batch1 = value;
+    else if (!strcmp(name, "use_local")) ix->use_local = value;
+    else if (!strcmp(name, "local_max_q")) ix->local_max_q = value;
+    else if (!strcmp(name, "local_m")) ix->local_m = std::max<int64_t>(0, std::min<int64_t>(value, 64));
     else if (!strcmp(name, "use_l1_tile")) ix->use_l1_tile = value;
     else if (!strcmp(name, "host_poll")) ix->host_poll = value;
     else if (!strcmp(name, "dyn_tiles")) ix->dyn_tiles = value;
@@ -359,10 +372,12 @@ extern "C" int hdb_set_option(hdb_index* ix, const char* name, int64_t value) {
     else if (!strcmp(name, "dyn_heavy")) ix->dyn_heavy = value;
     else if (!strcmp(name, "fused_timeout_us")) ix->fused_timeout_us = std::max<int64_t>(1, value);
     else if (!strcmp(name, "bits_fused")) ix->bits_fused = value;
+    else if (!strcmp(name, "bits_local")) ix->bits_local = value;
     else if (!strcmp(name, "fused_max_q")) ix->fused_max_q = value;
     else if (!strcmp(name, "f32_min_q")) ix->f32_min_q = value;
     else if (!strcmp(name, "bits_max_q")) ix->bits_max_q = value;
     else if (!strcmp(name, "profile")) { ix->profile = value; ix->ev_used = 0; }
+    else if (!strcmp(name, "host_timing_reset")) { ix->ht_pre_ns = ix->ht_launch_ns = ix->ht_wait_ns = ix->ht_calls = ix->ht_attr_ns = 0; }
     else return fail(HDB_ERR_ARG, std::string("hdb_set_option: unknown option ") + name);
     return HDB_OK;
 }
@@ -376,10 +391,16 @@ extern "C" int hdb_get_stat(hdb_index* ix, const char* name, int64_t* value) {
     else if (!strcmp(name, "mfma")) *value = ix->st_mfma;
     else if (!strcmp(name, "host_direct")) *value = ix->st_host_direct;
     else if (!strcmp(name, "fused")) *value = ix->st_fused;
+    else if (!strcmp(name, "local")) *value = ix->st_local;
     else if (!strcmp(name, "cand_cap")) *value = HDB_CAND_CAP;
     else if (!strcmp(name, "n")) *value = ix->n;
     else if (!strcmp(name, "ws_bytes")) *value = (int64_t)ix->ws_bytes;
     else if (!strcmp(name, "scan_launches")) *value = (int64_t)(ix->ev_used / 2);
+    else if (!strcmp(name, "host_pre_ns")) *value = ix->ht_pre_ns;
+    else if (!strcmp(name, "host_launch_ns")) *value = ix->ht_launch_ns;
+    else if (!strcmp(name, "host_wait_ns")) *value = ix->ht_wait_ns;
+    else if (!strcmp(name, "host_calls")) *value = ix->ht_calls;
+    else if (!strcmp(name, "host_attr_ns")) *value = ix->ht_attr_ns;
     else if (!strcmp(name, "scan_time_ns")) {      // sum over recorded launches; synchronises on the last event
         double total_ms = 0.0;
         for (size_t i = 0; i + 1 < ix->ev_used; i += 2) {
@@ -563,6 +584,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     const bool is_pearson = metric == HDB_PEARSON;
     // bit metrics tie massively by construction; the sampled threshold still works while the rows at and above its
     // level fit the candidate list (random data: yes), and the status word sends the rest through the exact path
+    const bool exact_req = exact;                            // the caller asked for the exact selection (tests; the re-run of a failed call)
     if (is_ham && !small && !ix->bits_fused) exact = true;
     if (ix->force_exact && !small) exact = true;
     if (!small && (int64_t)kk * 32 > n) exact = true;        // k is a large share of the rows: a sampled threshold cannot help
@@ -586,8 +608,20 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
                       hdb_mfma_supported(ix->dtype, ix->d, is_pearson ? (int)HDB_COSINE : metric);
     // 1-4 dot / cosine queries, k <= 128: one launch does everything (hdb_mfma_fused.h; fp16 on the matrix cores,
     // float32 in the VALU from the same staged tiles)
-    const bool fused_shape = ix->use_fused && !exact && !small && k <= HDB_MAX_K && dev_status != nullptr && !is_ham &&
-                             hdb_mfma_fused_supported(ix->dtype, ix->d, metric, nq, kk) && (ix->dtype == HDB_F32 || mfma) && nq <= fused_max_q &&
+    // Short matrices: the single launch in its LOCAL flavour -- no row sample, no exchange; every workgroup parks the scores of all
+    // its tiles and emits the rows at or above its own local_m-th best (hdb_mfma_fused.h).  Possible while a workgroup's tiles fit
+    // its parking area (fp16 d = 384: 16 tiles of 64 rows on 256 CUs = 262 144 rows); it also serves the matrices of up to 8192 rows
+    // the three-launch pipeline used to take (the reference's own sizes: 151 and 10 000 documents, tests/perf_hyperdb.py:15).
+    const int fl_rows = hdb_mfma_tile_rows(ix->dtype, ix->d);
+    const int64_t fl_tiles = fl_rows > 0 ? (n + fl_rows - 1) / fl_rows : 0;
+    int64_t fl_grid = std::min<int64_t>(fl_tiles, hdb_cu_count());
+    if (ix->max_blocks > 0) fl_grid = std::min<int64_t>(fl_grid, ix->max_blocks);
+    const int fl_cap = fl_rows > 0 && nq >= 1 && nq <= HDB_FUSED_MAXQ_RULE && nq <= ix->local_max_q ? hdb_mfma_fused_local_tiles(ix->dtype, ix->d, metric, nq) : 0;
+    const bool local_ok = fl_grid * 32 <= HDB_CAND_CAP && ix->use_fused && ix->use_local && !ix->force_exact && !exact_req && (ix->dtype == HDB_F32 || (ix->use_mfma && nq >= ix->mfma_min_q)) && fl_grid > 0 && fl_cap > 0 && (fl_tiles + fl_grid - 1) / fl_grid <= fl_cap &&
+                          !is_ham && kk <= 128 && dev_status != nullptr && hdb_mfma_fused_supported(ix->dtype, ix->d, metric, nq, kk);
+    if (local_ok) exact = false;                       // (k a large share of the rows: every workgroup then emits all its rows)
+    const bool fused_shape = ix->use_fused && !exact && (!small || local_ok) && k <= HDB_MAX_K && dev_status != nullptr && !is_ham &&
+                             hdb_mfma_fused_supported(ix->dtype, ix->d, metric, nq, kk) && (ix->dtype == HDB_F32 || mfma || local_ok) && (nq <= fused_max_q || local_ok) &&
                              // float32 d = 512 streams 32-KiB tiles (16 rows): below ~3 GB the five-kernel VALU pipeline is
                              // 2-5 % faster end to end (200 vs 210 us at 0.5 M rows, 376 vs 385 at 1 M; 728 vs 687 at 2 M)
                              !(ix->dtype == HDB_F32 && ix->d == 512 && n < 1500000) &&
@@ -640,7 +674,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     float* sbuf = b.take<float>((size_t)cq_max * (exact && !small ? ld_n : ld_s));
     float* kbuf = ksplit ? b.take<float>((size_t)cq_max * ld_n) : nullptr;
 
-    const bool fused = fused_shape && !full_sort && m == 8;           // (no prep kernel either)
+    const bool fused = fused_shape && !full_sort && (m == 8 || local_ok);           // (no prep kernel either)
     // the MFMA scan multiplies with fp16 queries: written by the same kernel (pearson converts its centred copy later)
     const bool f16_queries = mfma && ix->dtype == HDB_F16;          // fp32 matrices multiply with the float32 queries as they are
     const bool q16_in_prep = f16_queries && !is_pearson && !full_sort;
@@ -701,7 +735,8 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     // the MFMA scan has no mask input: excluded rows get a bias of -inf instead (never appended, like the VALU scan)
     const float* bias_eff = ix->bias;
     const uint8_t* mask_eff = ix->mask;
-    const bool l1tile = metric == HDB_MANHATTAN && ix->use_l1_tile && !small && hdb_l1_tile_supported(ix->dtype, ix->d);
+    // (run_scan hands manhattan calls of two or more queries to the tile kernel; a single query keeps the VALU scan and its mask input)
+    const bool l1tile = metric == HDB_MANHATTAN && ix->use_l1_tile && !small && nq >= 2 && hdb_l1_tile_supported(ix->dtype, ix->d);
     if ((mfma || fused || l1tile) && ix->mask) {
         if (n > ix->mbias_rows) {
             if (ix->mbias) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(ix->mbias)); ix->mbias = nullptr; }
@@ -712,7 +747,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
         LAUNCH_TRY(hdb_launch_maskbias(ix->mask, ix->bias, n, ix->mbias, st));
         bias_eff = ix->mbias; mask_eff = nullptr;
     }
-    ix->st_fused = 0;
+    ix->st_fused = 0; ix->st_local = 0;
     if (fused) {
         // ---- the whole call in ONE launch (hdb_mfma_fused.h): prep + sample + threshold + filter pass + finalize ----
         if (!ix->fctl) {
@@ -736,9 +771,21 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
         fa.ctl = reinterpret_cast<uint32_t*>(ix->fctl);
         fa.cand = cand; fa.cap = HDB_CAND_CAP; fa.k = (uint32_t)k; fa.kk = kk; fa.row_base = ix->row_base;
         fa.idx_out = dev_idx; fa.score_out = dev_score; fa.status = dev_status; fa.thr_out = thr;
+        if (local_ok) {
+            fa.local = 1;
+            // rows every workgroup emits at least: ~3072 candidates in all (8 .. 32 per workgroup); a grid too small to hold 4 k rows
+            // that way emits everything (64 = every lane maximum of a tile)
+            // slots of a workgroup in the (slotted) lists: 64 while the grid leaves room for them, else 32; never fewer than twice local_m
+            fa.local_slot = fl_grid * 64 <= HDB_CAND_CAP ? 64u : 32u;
+            fa.local_m = ix->local_m > 0 ? (uint32_t)ix->local_m
+                       : fl_grid * 32 >= 4 * (int64_t)kk ? (uint32_t)std::min<int64_t>(fa.local_slot / 2, std::max<int64_t>(8, (3072 + fl_grid - 1) / fl_grid)) : 64u;
+        }
+        ix->st_local = local_ok ? 1 : 0;
         ix->st_sample_rows = s_rows; ix->st_sample_m = m; ix->st_chunks = 1; ix->st_path = 1; ix->st_mfma = ix->dtype == HDB_F16 ? 1 : 0; ix->st_fused = 1;
         prof_begin(ix, st);
+        ix->ht_l0 = std::chrono::steady_clock::now();
         LAUNCH_TRY(hdb_launch_mfma_fused(&a, ix->dtype, &fa, (int)ix->max_blocks, st));
+        ix->ht_l1 = std::chrono::steady_clock::now();
         prof_end(ix, st);
         return HDB_OK;
     }
@@ -752,6 +799,13 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
             HIP_TRY(hipMemset(ix->bctl, 0, cb));
         }
         ix->st_sample_rows = s_rows; ix->st_sample_m = m; ix->st_chunks = 0; ix->st_path = 1; ix->st_mfma = 0; ix->st_fused = 3;
+        {   // (the launcher's rule: the local flavour from 2 k workgroups on, hdb_bits_fused.hip)
+            int64_t bl = hdb_cu_count();
+            const int64_t items = ((n + 15) / 16) * 4;
+            if (bl * 1024 > items) bl = (items + 1023) / 1024;
+            if (ix->max_blocks > 0 && ix->max_blocks < bl) bl = ix->max_blocks;
+            ix->st_local = (ix->bits_local && bl >= 2 * (int64_t)kk) ? 1 : 0;
+        }
         for (int q0 = 0; q0 < nq; q0 += 4) {
             const int cq = std::min(4, nq - q0);
             ix->st_chunks++;
@@ -760,6 +814,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
             ba.Qraw = static_cast<const float*>(dev_Q) + (size_t)q0 * ix->d; ba.nq = cq;
             ba.ntiles = (n + 15) / 16; ba.s_tiles = s_tiles; ba.s_stride = s_stride;
             ba.bias = ix->bias; ba.mask = ix->mask;
+            ba.local = ix->bits_local ? 1 : 0;
             ix->fused_epoch = (ix->fused_epoch + 1) & 0x7FFFFFFFu;
             if (ix->fused_epoch == 0) ix->fused_epoch = 1;
             ba.epoch = ix->fused_epoch;
@@ -768,7 +823,9 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
             ba.cand = cand; ba.cap = HDB_CAND_CAP; ba.k = (uint32_t)k; ba.kk = kk; ba.row_base = ix->row_base;
             ba.idx_out = dev_idx + (int64_t)q0 * k; ba.score_out = dev_score + (int64_t)q0 * k; ba.status = dev_status + q0;
             prof_begin(ix, st);
+            ix->ht_l0 = std::chrono::steady_clock::now();
             LAUNCH_TRY(hdb_launch_bits_fused(&ba, metric == HDB_JACCARD ? 1 : 0, (int)ix->max_blocks, st));
+            ix->ht_l1 = std::chrono::steady_clock::now();
             prof_end(ix, st);
         }
         return HDB_OK;
@@ -802,7 +859,9 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
             fa.k = (uint32_t)k; fa.kk = kk; fa.row_base = ix->row_base;
             fa.idx_out = dev_idx + (int64_t)q0 * k; fa.score_out = dev_score + (int64_t)q0 * k; fa.status = dev_status + q0;
             prof_begin(ix, st);
+            ix->ht_l0 = std::chrono::steady_clock::now();
             LAUNCH_TRY(hdb_launch_mfma_scan(&a, ix->dtype, 2, cq, nullptr, ix->sqnorm, nullptr, nullptr, (int)ix->max_blocks, (int)ix->mfma_variant, st, &fa));
+            ix->ht_l1 = std::chrono::steady_clock::now();
             prof_end(ix, st);
         }
         return HDB_OK;
@@ -947,6 +1006,7 @@ extern "C" int hdb_host_exchange_merge(void* shm, int64_t stride, int32_t world,
 extern "C" int hdb_topk_host(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, int metric, void* host_record, void* stream) {
     if (!ix || !host_record) return fail(HDB_ERR_ARG, "hdb_topk_host: null argument");
     if (nq <= 0 || k <= 0) return fail(HDB_ERR_ARG, "hdb_topk_host: nq and k must be positive");
+    const auto ht0 = std::chrono::steady_clock::now();
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t st = (hipStream_t)stream;
     const size_t bytes = (size_t)hdb_packed_bytes(nq, k);
@@ -957,6 +1017,7 @@ extern "C" int hdb_topk_host(hdb_index* ix, const void* dev_Q, int32_t nq, int32
         hipPointerAttribute_t attr;
         if (hipPointerGetAttributes(&attr, host_record) == hipSuccess) direct = attr.type == hipMemoryTypeHost && attr.devicePointer == host_record;
         else (void)hipGetLastError();
+        ix->ht_attr_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - ht0).count();
     }
     ix->st_host_direct = direct ? 1 : 0;
     char* rec = static_cast<char*>(host_record);
@@ -978,6 +1039,7 @@ extern "C" int hdb_topk_host(hdb_index* ix, const void* dev_Q, int32_t nq, int32
     constexpr int32_t SENTINEL = 0x7FFFFFFF;
     volatile int32_t* poll = reinterpret_cast<volatile int32_t*>(static_cast<char*>(host_record) + (size_t)nq * k * 12);
     if (direct && ix->host_poll) for (int q = 0; q < nq; ++q) poll[q] = SENTINEL;
+    ix->ht_l0 = ix->ht_l1 = std::chrono::steady_clock::now();      // (pipelines of several launches: everything counts as "pre")
     int rc = topk_impl(ix, dev_Q, nq, k, metric, d_idx, d_sc, d_st, stream, false);
     if (rc) return rc;
     if (!direct) HIP_TRY(hipMemcpyAsync(host_record, rec, bytes, hipMemcpyDeviceToHost, st));
@@ -994,6 +1056,14 @@ extern "C" int hdb_topk_host(hdb_index* ix, const void* dev_Q, int32_t nq, int32
         std::atomic_thread_fence(std::memory_order_acquire);
     }
     if (!polled) HIP_TRY(hipStreamSynchronize(st));
+    {
+        const auto ht3 = std::chrono::steady_clock::now();
+        using ns = std::chrono::nanoseconds;
+        ix->ht_pre_ns += std::chrono::duration_cast<ns>(ix->ht_l0 - ht0).count();
+        ix->ht_launch_ns += std::chrono::duration_cast<ns>(ix->ht_l1 - ix->ht_l0).count();
+        ix->ht_wait_ns += std::chrono::duration_cast<ns>(ht3 - ix->ht_l1).count();
+        ix->ht_calls++;
+    }
     const int32_t* h_st = reinterpret_cast<const int32_t*>(static_cast<const char*>(host_record) + (size_t)nq * k * 12);
     bool any_bad = false;
     for (int q = 0; q < nq; ++q) any_bad |= (h_st[q] & (HDB_Q_UNDERFLOW | HDB_Q_OVERFLOW)) != 0;

@@ -19,6 +19,14 @@
 //             idle until then) and go to the per-query candidate lists with one atomic per query at the end;
 //   finish    drain, agent-scope release, arrive; when every workgroup has arrived, the owner of each query sorts its list
 //             (hdb_finalize_body) and writes the k results and the status word; the last workgroup out zeroes the counters.
+// Round 4 (BitsArgs::local, the default): no row sample and no exchange.  Every wave scores its first piece; the 8-th best of the
+// workgroup's first 4096 rows is that workgroup's filter threshold b0; at the end of the pass the 8-th best b_w of everything it
+// collected (>= b0) is taken and ONLY the rows at or above b_w -- all of them, ties included -- go to the global lists, with b_w in
+// the granule area.  A row that was not emitted scores below its workgroup's b_w, so the union holds the global top-k (under the
+// build's order: score descending, row ascending) as soon as every b_w is <= the k-th best score of the union; the owner of a
+// query checks that and reports UNDERFLOW otherwise (host: exact re-run).  This drops the sample pass (its tiles were read twice:
+// +6 % HBM traffic at N = 10M), the publish / sweep / poll round trips (~8 us) and every cross-workgroup dependency before the
+// arrival counter.  P(a workgroup holds 8 of the 99 best rows of random data) = 2e-6 per call at 256 workgroups.
 // Scores are small integers (hamming) with massive ties: everything at the threshold's own level survives, the sample plan aims
 // lower for that (sample_plan's `coarse`), and an overflowing list comes back as HDB_Q_OVERFLOW for the exact path.
 // Every spin is bounded (s_memrealtime); a workgroup that gives up raises the abort word: statuses become HDB_Q_UNDERFLOW and
@@ -189,7 +197,8 @@ __global__ __launch_bounds__(HDB_BITS_THREADS) void hdb_bits_fused_kernel(BitsAr
     uint32_t top0[QH], top1[QH];
 #pragma unroll
     for (int qq = 0; qq < QH; ++qq) { top0[qq] = 0u; top1[qq] = 0u; }
-    for (int64_t j = (int64_t)tid * G + b; j < a.s_tiles * 4; j += G * HDB_BITS_THREADS) {      // (every workgroup takes a share: the sample is ~20 k quads)
+    const bool local = a.local != 0;
+    for (int64_t j = (int64_t)tid * G + b; !local && j < a.s_tiles * 4; j += G * HDB_BITS_THREADS) {      // (every workgroup takes a share: the sample is ~20 k quads)
         const int64_t i = hdb_tile_index(j >> 2, a.s_stride) * 4 + (j & 3);
         if (4 * i >= a.npad) continue;
         float s[QH][4];
@@ -208,7 +217,7 @@ __global__ __launch_bounds__(HDB_BITS_THREADS) void hdb_bits_fused_kernel(BitsAr
     // ---- publish this workgroup's eight largest per query: granules [query][workgroup][8] x {epoch, key}
 #pragma unroll
     for (int qq = 0; qq < QH; ++qq) {
-        if (qq < nq) {
+        if (qq < nq && !local) {
             const uint32_t r8 = hdb_wg_top8(top0[qq], top1[qq], scratch);
             if (w == 0) {
                 const uint32_t k0 = (uint32_t)__shfl((int)r8, 2 * (lane & 3), 64), k1 = (uint32_t)__shfl((int)r8, 2 * (lane & 3) + 1, 64);
@@ -223,7 +232,7 @@ __global__ __launch_bounds__(HDB_BITS_THREADS) void hdb_bits_fused_kernel(BitsAr
     const unsigned long long x_t0 = __builtin_amdgcn_s_memrealtime();
     HDB_XSTAMP(3);
     // ---- owners: workgroup q sweeps the G x 8 granules of query q (NG / 2 pairs of granules, one 16-byte load per thread and step)
-    for (int q = (int)b; q < nq; q += (int)G) {
+    for (int q = (int)b; !local && q < nq; q += (int)G) {
         const char* srcb = reinterpret_cast<const char*>(a.ctl) + HDB_BATCH_GRAN_BYTE + (int64_t)q * G * 64;
         const int NP = (int)G * 4;
         bool gave_up = false;
@@ -317,8 +326,25 @@ __global__ __launch_bounds__(HDB_BITS_THREADS) void hdb_bits_fused_kernel(BitsAr
         i0 += lane;
         if (4 * i0 < a.npad) live0 = score_quad(i0, s0);
     }
+    // ---- local flavour: the threshold is the 8-th best of this workgroup's first pieces (fewer rows than that: none)
+    if (local) {
+#pragma unroll
+        for (int qq = 0; qq < QH; ++qq) {
+            if (qq < nq) {                                     // (workgroup-uniform)
+                uint32_t t0 = 0u, t1 = 0u;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t key = ((live0 >> u) & 1u) ? hdb_f2key(s0[qq][u]) : 0u;
+                    const uint32_t lo = min(t0, key);
+                    t0 = max(t0, key); t1 = max(t1, lo);
+                }
+                const uint32_t r8 = hdb_wg_top8(t0, t1, scratch);
+                if (w == 0 && lane == 7) xthr[qq] = r8 ? hdb_key2f(r8) : -INFINITY;
+            }
+        }
+    }
     // ---- everybody: thread t fetches the threshold word of query t
-    if (tid < nq) {
+    if (!local && tid < nq) {
         unsigned long long v;
         for (;;) {
             if (HDB_BITS_POLL) v = __hip_atomic_fetch_or(thrw + tid, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -379,7 +405,42 @@ __global__ __launch_bounds__(HDB_BITS_THREADS) void hdb_bits_fused_kernel(BitsAr
     for (int qq = 0; qq < QH; ++qq) {
         if (qq < nq) {
             const uint32_t have = min(lcnt[qq], LCAP);
-            if (have > 0u) {                                     // (workgroup-uniform)
+            if (local) {
+                // b_w = the 8-th best of what this workgroup collected (every thread brings the two best of its share of the list;
+                // a list longer than two entries per thread makes it a lower bound of the 8-th best, which is all the check needs)
+                uint32_t t0 = 0u, t1 = 0u;
+                for (uint32_t e = tid; e < have; e += HDB_BITS_THREADS) {
+                    const uint32_t key = (uint32_t)(lbuf[(uint32_t)qq * LCAP + e] >> 32);
+                    const uint32_t lo = min(t0, key);
+                    t0 = max(t0, key); t1 = max(t1, lo);
+                }
+                const uint32_t r8 = hdb_wg_top8(t0, t1, scratch);
+                if (tid == 7) { xflag[14] = r8; xflag[15] = 0u; }       // (lane 7 of wave 0: the 8-th largest; 0 = fewer than eight: everything goes)
+                __syncthreads();
+                const uint32_t bkey = xflag[14];
+                uint32_t mine = 0u;
+                for (uint32_t e = tid; e < have; e += HDB_BITS_THREADS) mine += (uint32_t)(lbuf[(uint32_t)qq * LCAP + e] >> 32) >= bkey ? 1u : 0u;
+                if (mine) atomicAdd(&xflag[15], mine);
+                __syncthreads();
+                const uint32_t npass = xflag[15];
+                if (tid == 0) {
+                    xflag[14] = npass ? atomicAdd(&gcnt[qq], npass) : 0u;
+                    xflag[15] = 0u;
+                    // b_w for the owner's check (scores here are final scores: no domain to convert)
+                    __hip_atomic_store((hdb_bgu64*)(reinterpret_cast<char*>(a.ctl) + HDB_BATCH_GRAN_BYTE + ((int64_t)qq * G + b) * 64),
+                                       (unsigned long long)bkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+                const uint32_t base = xflag[14];
+                for (uint32_t e = tid; e < have; e += HDB_BITS_THREADS) {
+                    const unsigned long long ent = lbuf[(uint32_t)qq * LCAP + e];
+                    if ((uint32_t)(ent >> 32) >= bkey) {
+                        const uint32_t pos = base + atomicAdd(&xflag[15], 1u);
+                        if (pos < a.cap) a.cand[(int64_t)qq * a.cap + pos] = ent;
+                    }
+                }
+                __syncthreads();
+            } else if (have > 0u) {                              // (workgroup-uniform)
                 if (tid == 0) xflag[14] = atomicAdd(&gcnt[qq], have);
                 __syncthreads();
                 const uint32_t base = xflag[14];
@@ -417,8 +478,23 @@ __global__ __launch_bounds__(HDB_BITS_THREADS) void hdb_bits_fused_kernel(BitsAr
     for (int q = (int)b; q < nq; q += (int)G) {
         const uint32_t tot0 = __hip_atomic_load(gcnt + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int qn = (int)xflag[q];
-        hdb_finalize_body(fbuf, a.cand + (int64_t)q * a.cap, aborted ? 0u : tot0, q, a.cap, a.k, a.kk, a.row_base, a.idx_out, a.score_out,
-                          a.status, qn, 0);
+        uint32_t floor_key = 0u;
+        if (local) {
+            // the highest b_w of any workgroup: the list is complete for every score >= it, so the top-k is exact iff the k-th best of
+            // the union is >= it (the floor test is strict: one key below)
+            uint32_t bk = 0u;
+            for (int64_t wg = tid; wg < G; wg += HDB_BITS_THREADS)
+                bk = max(bk, (uint32_t)__hip_atomic_load((hdb_bgu64*)(reinterpret_cast<char*>(a.ctl) + HDB_BATCH_GRAN_BYTE + ((int64_t)q * G + wg) * 64),
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            bk = hdb_wave_max_dpp(bk);
+            if (lane == 0) scratch[w] = bk;
+            __syncthreads();
+            for (int w2 = 0; w2 < HDB_BITS_WAVES; ++w2) floor_key = max(floor_key, scratch[w2]);
+            floor_key = floor_key ? floor_key - 1u : 0u;
+            __syncthreads();
+        }
+        hdb_finalize_fast(fbuf, a.cand + (int64_t)q * a.cap, aborted ? 0u : tot0, q, a.cap, a.k, a.kk, a.row_base, a.idx_out, a.score_out,
+                          a.status, qn, 0, nullptr, 1.f, HdbNoFix(), local, floor_key);
         __syncthreads();
     }
     __syncthreads();
@@ -452,6 +528,10 @@ extern "C" int hdb_launch_bits_fused(const BitsArgs* args, int jaccard, int max_
     if ((int64_t)blocks * HDB_BITS_THREADS > items) blocks = (int)((items + HDB_BITS_THREADS - 1) / HDB_BITS_THREADS);
     if (max_blocks > 0 && max_blocks < blocks) blocks = max_blocks;
     if (blocks < 1) blocks = 1;
+    // the local flavour needs every workgroup's share of the k best rows far below the 8 it emits at least: grids of 2 k workgroups
+    // and more (k = 100: matrices of 820k rows and more; P(Poisson(0.5) >= 8) = 2e-7 per workgroup), else the exchange flavour
+    BitsArgs a_eff = a;
+    if ((int64_t)blocks < 2 * (int64_t)a.kk) a_eff.local = 0;
     const bool nt = (size_t)a.npad * a.W * 4 > ((size_t)256 << 20);      // the sign bits do not fit the Infinity Cache: stream them past it (5M x 384 = 240 MB still gain from it)
 #define HDB_BITS_LAUNCH(JAC_, QH_)                                                                                          \
     do {                                                                                                                    \
@@ -459,7 +539,7 @@ extern "C" int hdb_launch_bits_fused(const BitsArgs* args, int jaccard, int max_
         static unsigned long long attr_done[2] = {0, 0};                                                                    \
         hipError_t e = hdb_lds_attr_once(reinterpret_cast<const void*>(kern), (int)lds, &attr_done[nt ? 1 : 0]);            \
         if (e != hipSuccess) return (int)e;                                                                                 \
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(HDB_BITS_THREADS), lds, st, a);                                         \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(HDB_BITS_THREADS), lds, st, a_eff);                                     \
     } while (0)
     if (a.nq == 1) { if (jaccard) HDB_BITS_LAUNCH(true, 1); else HDB_BITS_LAUNCH(false, 1); }
     else if (a.nq == 2) { if (jaccard) HDB_BITS_LAUNCH(true, 2); else HDB_BITS_LAUNCH(false, 2); }

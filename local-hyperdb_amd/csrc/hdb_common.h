@@ -64,6 +64,12 @@ struct FusedArgs {
     int64_t row_base;
     int64_t* idx_out; float* score_out; int32_t* status;
     float* thr_out;                 // [nq] thresholds (diagnostics)
+    // "local" flavour (round 4, short matrices: every workgroup's tiles fit its parking area): no row sample and no exchange -- a
+    // workgroup parks the scores of ALL its tiles, takes the local_m-th largest (a lower bound of it) as ITS OWN threshold and emits
+    // the rows at or above it; the last workgroup checks that no workgroup's threshold reaches the k-th best of the union.
+    // Its lists are SLOTTED: workgroup w writes its rows of query q to cand[q][w * local_slot ...] and leaves {count, b_w} in the
+    // granule area -- no slot reservation, no atomic (fp16 euclidean excepted: its near-duplicate re-score wants a compact list).
+    int32_t local; uint32_t local_m; uint32_t local_slot;
 };
 
 // Extra arguments of the single-launch BATCHED top-k (hdb_mfma_kernel.h, MODE 2): up to 256 queries, one launch does query
@@ -130,6 +136,10 @@ struct BitsArgs {
     unsigned long long* cand; uint32_t cap, k, kk;
     int64_t row_base;
     int64_t* idx_out; float* score_out; int32_t* status;
+    // round 4: no row sample and no exchange -- every workgroup filters with the 8-th best score of its OWN first pieces, keeps the
+    // rows at or above the 8-th best of everything it collected (ties included) and the owner of a query checks those thresholds
+    // against the k-th best of the union (hdb_bits_fused.hip)
+    int32_t local;
 };
 
 // ---- fp16 copy of a query for the matrix pipe ----------------------------------------------------------

@@ -171,12 +171,159 @@ __device__ __forceinline__ uint32_t hdb_finalize_body(unsigned long long* buf, c
             int32_t st = extra_status;
             if (total > cap) st |= HDB_Q_OVERFLOW;
             if (nc < kk) st |= HDB_Q_UNDERFLOW;
+            if (floor_ptr && kk > 0 && ctl[8] == 0u) st |= HDB_Q_UNDERFLOW;      // the k-th best does not clear the floor: the list may be incomplete
             if (qnan_flag) st |= HDB_Q_NAN;
             __hip_atomic_store(status + q, st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     uint32_t kth_above = 0;
     if (floor_ptr) { __syncthreads(); kth_above = ctl[8]; }
+    return kth_above;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same step with the candidates in REGISTERS (round 4): the usual case -- a few hundred to a few thousand candidates, k <= 256 --
+// needs no LDS copy of the list, no separate min/max pass and no copy-back: four barriers instead of eleven
+// (profiles/r4_finalize_fast.txt).  Loads -> per-wave min/max (DPP) -> 1024 shift bins between the smallest and the largest key ->
+// wave 0 alone scans the bins from the top -> entries in or above the bin of the kk-th largest go to a short LDS list -> rank sort.
+// Anything else (more than 8 entries per thread, a fix-up functor, very short or very tie-heavy lists) takes hdb_finalize_body;
+// both produce identical results (the survivors always contain the true top-kk; the order is the total order of the packed entries).
+// `have_floor_key`: the caller passes the floor as an orderable key of the SCORE domain instead of floor_ptr / floor_mul.
+// LDS: hist (1024 u32) | wave minima / maxima (32 u32) | ctl (16 u32) | survivors (1024 u64) = 12.5 KiB at `buf`.
+// ------------------------------------------------------------------------------------------------
+template <typename A, typename B> struct HdbSame { static constexpr bool value = false; };
+template <typename A> struct HdbSame<A, A> { static constexpr bool value = true; };
+
+template <typename Fix = HdbNoFix>
+__device__ __forceinline__ uint32_t hdb_finalize_fast(unsigned long long* buf, const unsigned long long* cand, uint32_t total, int q,
+                                                      uint32_t cap, uint32_t k, uint32_t kk /* min(k, n) */, int64_t row_base,
+                                                      int64_t* idx_out, float* score_out, int32_t* status, int qnan_flag,
+                                                      int32_t extra_status, const float* floor_ptr = nullptr, float floor_mul = 1.f,
+                                                      const Fix& fix = Fix(), bool have_floor_key = false, uint32_t floor_key_in = 0u,
+                                                      const uint32_t* slot_cnt = nullptr, uint32_t slot_size = 0u, uint32_t slot_wgs = 0u) {
+    // Slotted lists (the local flavour of hdb_mfma_fused.h): workgroup w left slot_cnt[w] (LDS) entries at cand[w * slot_size ...];
+    // `total` is their sum.  Such a list is only ever read here (it is not compact: hdb_finalize_body cannot take it), so this path
+    // serves every size of it; ties too massive for the survivor list come back as "k-th best not above the floor" (0).
+    constexpr int NE = 16;
+    constexpr uint32_t NB = 1024, SCAP = 1024;
+    const bool slotted = slot_cnt != nullptr;
+    const uint32_t nc = total < cap ? total : cap;
+    const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nth >> 6;
+    const uint32_t nload = slotted ? slot_wgs * slot_size : nc;      // list positions to look at
+    const int slot_sh = slotted ? 31 - __clz((int)slot_size) : 0;
+    const bool fast = slotted || (HdbSame<Fix, HdbNoFix>::value && nc > 256u && nc <= (uint32_t)(NE * nth) && kk <= 256u && kk > 0u && nw <= 16);
+    if (!fast) {
+        if (have_floor_key) {                        // (hdb_finalize_body takes its floor through memory: park the key in its ctl area)
+            float* fk = reinterpret_cast<float*>(reinterpret_cast<uint32_t*>(buf + 2 * (size_t)cap) + 2048 + 12);
+            if (tid == 0) *fk = hdb_key2f(floor_key_in);
+            __syncthreads();
+            return hdb_finalize_body(buf, cand, total, q, cap, k, kk, row_base, idx_out, score_out, status, qnan_flag, extra_status, fk, 1.f, fix);
+        }
+        return hdb_finalize_body(buf, cand, total, q, cap, k, kk, row_base, idx_out, score_out, status, qnan_flag, extra_status, floor_ptr, floor_mul, fix);
+    }
+    uint32_t* hist = reinterpret_cast<uint32_t*>(buf);
+    uint32_t* wred = hist + NB;
+    uint32_t* ctl = wred + 32;
+    unsigned long long* sbuf = reinterpret_cast<unsigned long long*>(ctl + 16);
+    HDB_FIN_STAMP(8);
+    float floor_v = 0.f;
+    if (floor_ptr && !have_floor_key) floor_v = __hip_atomic_load(floor_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned long long e[NE];
+    bool ev[NE];                                     // position j of this thread holds an entry
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        const uint32_t i = (uint32_t)(tid + j * nth);
+        ev[j] = i < nload && (!slotted || (i & (slot_size - 1u)) < slot_cnt[i >> slot_sh]);      // (slot_size is a power of two)
+        e[j] = ev[j] ? cand[i] : 0ull;
+    }
+    for (uint32_t i = tid; i < NB; i += nth) hist[i] = 0u;
+    if (tid < 16) ctl[tid] = 0u;
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+    for (int j = 0; j < NE; ++j)
+        if (ev[j]) { const uint32_t kx = (uint32_t)(e[j] >> 32); kmin = min(kmin, kx); kmax = max(kmax, kx); }
+    kmin = ~hdb_wave_max_dpp(~kmin);
+    kmax = hdb_wave_max_dpp(kmax);
+    if (lane == 0) { wred[wave] = kmin; wred[16 + wave] = kmax; }
+    __syncthreads();
+    HDB_FIN_STAMP(9);
+    for (int w2 = 0; w2 < nw; ++w2) { kmin = min(kmin, wred[w2]); kmax = max(kmax, wred[16 + w2]); }
+    if (kmin > kmax) { kmin = 0u; kmax = 0u; }       // (an empty list)
+    const uint32_t range = kmax - kmin;
+    const int bits = range ? 32 - __clz((int)range) : 0;
+    const int sh = bits > 10 ? bits - 10 : 0;
+#pragma unroll
+    for (int j = 0; j < NE; ++j)
+        if (ev[j]) atomicAdd(&hist[((uint32_t)(e[j] >> 32) - kmin) >> sh], 1u);
+    __syncthreads();
+    if (wave == 0) {                                 // bins from the top: lane l owns bins NB-1-16l .. NB-16-16l
+        uint32_t loc[16], tot = 0u;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { loc[j] = hist[NB - 1 - (16 * lane + j)]; tot += loc[j]; }
+        uint32_t incl = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+        uint32_t before = incl - tot;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (before < kk && kk <= before + loc[j]) ctl[2] = NB - 1 - (uint32_t)(16 * lane + j);      // the bin holding the kk-th largest (none: fewer than kk entries, bin 0 = everything)
+            before += loc[j];
+        }
+    }
+    __syncthreads();
+    const uint32_t bsel = ctl[2];
+#pragma unroll
+    for (int j = 0; j < NE; ++j)
+        if (ev[j] && (((uint32_t)(e[j] >> 32) - kmin) >> sh) >= bsel) {
+            const uint32_t pos = atomicAdd(&ctl[3], 1u);
+            if (pos < SCAP) sbuf[pos] = e[j];
+        }
+    __syncthreads();
+    HDB_FIN_STAMP(10);
+    const uint32_t ns = ctl[3];
+    if (ns > SCAP || ns > (uint32_t)nth) {           // massive ties around the kk-th score: the general path sorts them (workgroup-uniform branch)
+        __syncthreads();
+        if (slotted) return 0u;                      // (no compact list to hand over: reported as a failed floor check, the caller's exact re-run sorts it out)
+        if (have_floor_key) {
+            float* fk = reinterpret_cast<float*>(reinterpret_cast<uint32_t*>(buf + 2 * (size_t)cap) + 2048 + 12);
+            if (tid == 0) *fk = hdb_key2f(floor_key_in);
+            __syncthreads();
+            return hdb_finalize_body(buf, cand, total, q, cap, k, kk, row_base, idx_out, score_out, status, qnan_flag, extra_status, fk, 1.f, fix);
+        }
+        return hdb_finalize_body(buf, cand, total, q, cap, k, kk, row_base, idx_out, score_out, status, qnan_flag, extra_status, floor_ptr, floor_mul, fix);
+    }
+    const bool want_floor = floor_ptr != nullptr || have_floor_key;
+    const uint32_t floor_key = have_floor_key ? floor_key_in : (floor_ptr ? hdb_f2key(hdb_canon(floor_v * floor_mul)) : 0u);
+    const uint32_t nout = nc < kk ? nc : kk;
+    for (uint32_t i = nout + tid; i < k; i += nth) { idx_out[(int64_t)q * k + i] = -1; score_out[(int64_t)q * k + i] = -INFINITY; }
+    if ((uint32_t)tid < ns) {
+        const unsigned long long mine = sbuf[tid];
+        uint32_t rank = 0, j = 0;
+        for (; j + 2 <= ns; j += 2) {
+            const ulonglong2 pr = *reinterpret_cast<const ulonglong2*>(sbuf + j);
+            rank += (pr.x > mine) + (pr.y > mine);
+        }
+        if (j < ns) rank += sbuf[j] > mine;
+        if (rank < nout) {
+            idx_out[(int64_t)q * k + rank] = row_base + (int64_t)(0xFFFFFFFFu - (uint32_t)(mine & 0xFFFFFFFFull));
+            score_out[(int64_t)q * k + rank] = hdb_key2f((uint32_t)(mine >> 32));
+        }
+        if (want_floor && rank == kk - 1) ctl[8] = (uint32_t)(mine >> 32) > floor_key ? 1u : 0u;      // the kk-th best
+    }
+    if (status) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            int32_t st = extra_status;
+            if (total > cap) st |= HDB_Q_OVERFLOW;
+            if (nc < kk) st |= HDB_Q_UNDERFLOW;
+            if (want_floor && kk > 0 && ctl[8] == 0u) st |= HDB_Q_UNDERFLOW;      // (see hdb_finalize_body)
+            if (qnan_flag) st |= HDB_Q_NAN;
+            __hip_atomic_store(status + q, st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    uint32_t kth_above = 0;
+    if (want_floor) { __syncthreads(); kth_above = ctl[8]; }
     return kth_above;
 }
 

@@ -146,7 +146,8 @@ extern "C" int hdb_launch_mfma_scan(const ScanArgs* args, int dtype, int mode, i
     if (hdb_mfma_ksplit_slices(dtype, a.d) > 0) return mode == 2 ? (int)hipErrorNotSupported : hdb_launch_mfma_ksplit(args, dtype, mode, nq_launch, q16, sqnorm, qsq, qscl, blocks, stream);
     if (dtype == HDB_F32) return hdb_launch_mfma_scan_f32(args, mode, nq_launch, q16, sqnorm, qsq, blocks, stream, f);
     if (dtype != HDB_F16) return (int)hipErrorNotSupported;
-    if (nq_launch > 128 && hdb_mfma_qt2_supported(a.d) && g_mfma_variant != 32)
+    // (mode 2 promises hdb_mfma_batch_capacity() queries in ONE launch: only the two-tile launcher holds more than 128, whatever the variant)
+    if (nq_launch > 128 && hdb_mfma_qt2_supported(a.d) && (g_mfma_variant != 32 || (mode == 2 && a.d != 384)))
         return hdb_launch_mfma_scan_f16_qt2(args, mode, nq_launch, q16, sqnorm, qsq, qscl, blocks, stream, f);
     const int v = g_mfma_variant;
     switch (a.d) {

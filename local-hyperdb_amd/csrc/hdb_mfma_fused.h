@@ -26,6 +26,14 @@
 //   finish    survivors go to the global candidate lists (atomics); each workgroup drains, releases and takes a
 //             ticket; the LAST workgroup re-uses the ring LDS to pre-select, sort and write the k results (and the
 //             status words) of every query, straight into the caller's (pinned host or device) buffers.
+// Short matrices (round 4, FusedArgs::local): when all tiles of a workgroup fit its parking area (<= 16 tiles for 1-2 queries)
+// there is no phase A and no exchange at all.  Wave 0 parks the scores of every tile; after the last tile wave q takes the
+// local_m-th largest of the lane maxima of query q as the workgroup's own threshold b_w (at least local_m rows reach it),
+// reserves its slots in the global list with ONE atomic and writes the rows at or above b_w straight from the parked scores.
+// Any row a workgroup did not emit scores below that workgroup's b_w, so the union holds the global top-k as soon as every b_w
+// lies strictly below the k-th best of the union: the last workgroup checks exactly that (the b_w travel as score-domain keys
+// in the granule area) and reports UNDERFLOW otherwise -- the host then re-runs the call through the exact path, as for a
+// failed sampled threshold.  Random rows: P(some workgroup holds local_m = 12 of the 99 best) ~ 1e-12 per call.
 // Every spin is bounded by a wall-clock timeout (s_memrealtime): a workgroup that gives up publishes nothing harmful,
 // filters with threshold +inf, and raises the abort word, which turns every status into HDB_Q_UNDERFLOW so that the
 // host re-runs the call through the exact path (and resets the control block).  This only happens when the grid is
@@ -154,7 +162,9 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     // ---- tile sequence: phase A (sample) then phase B (all rows) through ONE ring ------------------
     const char* const Vb = reinterpret_cast<const char*>(a.V);
     const int64_t n_rows = a.n;
-    const int64_t nA = f.s_tiles > b ? (f.s_tiles - b + G - 1) / G : 0;
+    const bool local = PARK && f.local != 0;         // no sample, no exchange: the workgroup's own threshold (see the header)
+    constexpr bool SLOTTED = !(METRIC == 2 && sizeof(E) == 2);      // ... and its lists are slotted (FusedArgs::local_slot)
+    const int64_t nA = local ? 0 : (f.s_tiles > b ? (f.s_tiles - b + G - 1) / G : 0);
     // Phase B hands out its tiles DYNAMICALLY, in chunks of CH consecutive tiles: the first S chunks of a workgroup are
     // fixed (chunk c -> tiles (c*G + b)*CH ...), every later one comes from a global counter (f.ctl[32], a cache line
     // of its own: ~35 requests per us at N = 10M).  With a static split the slowest workgroup finished 15-25 us after the
@@ -168,8 +178,9 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     // A request covers ~192 KiB of V (4 tiles of 48 KiB, 6 of 32, 12 of 16): tiles of 28-40 KiB stream in 1.0-1.4 us, and four
     // of them per request put G / (4 x 1.1 us) = 58 requests per us on the counter (d=1024: 1.53 us per tile instead of 1.15).
     constexpr int64_t CHL = (4 * 48 * 1024 + STAGE - 1) / STAGE;
-    const int64_t CH = ntiles >= 2 * CHL * G ? CHL : 1;      // size of the fixed chunks (and of the large requests)
-    const int64_t S = ntiles >= 8 * CHL * G ? 1 : ntiles >= 2 * CHL * G ? ntiles / (2 * CHL * G) : (ntiles + G - 1) / G;
+    // (local flavour: a fixed split, tile t -> workgroup t mod G, so that nobody exceeds its parking area)
+    const int64_t CH = (!local && ntiles >= 2 * CHL * G) ? CHL : 1;      // size of the fixed chunks (and of the large requests)
+    const int64_t S = local ? (ntiles + G - 1) / G : ntiles >= 8 * CHL * G ? 1 : ntiles >= 2 * CHL * G ? ntiles / (2 * CHL * G) : (ntiles + G - 1) / G;
     const int64_t dyn0 = S * G * CH;                 // first tile handed out by the counter
     unsigned int* dq = ctl + 4;                      // [2][2] {first tile - dyn0, length} handed over by wave 7
     const unsigned int dq_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(dq);
@@ -387,7 +398,11 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
     // Comparison domain of the filter == domain of the sample scores (identical arithmetic in both phases): the raw
     // dot (x 1/||v|| for cosine) without bias, the finished score with bias.
     float thr_cmp = INFINITY;
-    bool direct = false;                             // survivors straight to the global lists (while cb still holds parked scores)
+    // Entries the LDS list may hold right now.  While parked tiles are being filtered the list grows into the part of the parking
+    // area that has been consumed (tile p read -> its bytes are free); only what does not fit goes straight to the global lists,
+    // one atomic per entry.  (Round 3 sent every survivor of a parked tile there: on short matrices, where all tiles are parked,
+    // 256 workgroups then queued 2-4 k returning atomics on one counter word -- 10-20 us at N = 100k.)
+    unsigned int cb_lim = CB;
     auto filter = [&](const Acc (&tv)[RT], int64_t row0) {
         float gm[RT];
 #pragma unroll
@@ -405,14 +420,15 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                         const float x = tv[rt][j];
                         if (x >= thr_cmp && q_ok && rowg + j < n_rows && !(HAS_BIAS && x == -INFINITY)) {
                             const float sc = hdb_canon((HAS_BIAS || METRIC == 2) ? x : x * qinv_l);
-                            unsigned int pos = CB;
-                            if (!(PARK && direct)) asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)"
-                                                      : "=&v"(pos) : "v"(ctl_addr), "v"(1u) : "memory");
-                            if (pos < CB) {
+                            unsigned int pos;
+                            asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(pos) : "v"(ctl_addr), "v"(1u) : "memory");
+                            if (pos < cb_lim) {
                                 const unsigned long long ent = hdb_pack(sc, (uint32_t)(rowg + j));
                                 asm volatile("ds_write_b64 %0, %1\n\tds_write_b16 %2, %3"
                                              :: "v"(cb_addr + pos * 8u), "v"(ent), "v"(cbq_addr + pos * 2u), "v"((unsigned int)rl) : "memory");
                             } else {
+                                // (a limited list: give the slot back -- only this wave touches the counter, and the kept slots are the low ones)
+                                if (PARK && cb_lim < (unsigned int)CB) asm volatile("ds_add_u32 %0, %1" :: "v"(ctl_addr), "v"(0xFFFFFFFFu) : "memory");
                                 const unsigned int gpos = atomicAdd(&f.ctl[2 + rl], 1u);
                                 if (gpos < f.cap) f.cand[(int64_t)rl * f.cap + gpos] = hdb_pack(sc, (uint32_t)(rowg + j));
                             }
@@ -521,7 +537,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
         // sweep that finds only part of the granules tagged with this call's epoch already yields a safe (merely less
         // selective) threshold: the filter pass starts on it and later sweeps raise it.  Nothing waits for the slowest
         // workgroup, and a grid that is not fully resident cannot block (see the header).
-        if (selector) {
+        if (selector && !local) {
 #pragma unroll
             for (int qq = 0; qq < 2; ++qq) {
                 const int q = 2 * (w - 1) + qq;
@@ -844,7 +860,6 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                     ++npend;
                 } else {
                     if (PARK && npend > 0) {
-                        direct = true;               // the parked scores sit where the candidate list would grow
 #pragma unroll 1
                         for (int p = 0; p < npend; ++p) {
                             Acc tv[RT];
@@ -854,9 +869,12 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                                 if (q_ok) asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(pbuf_addr + (unsigned int)p * pend_stride + pslot + (unsigned int)rt * 64u) : "memory");
                                 tv[rt] = v;
                             }
+                            // the parked scores sit where the candidate list grows: it may use the bytes of tiles 0 .. p, now in registers
+                            const unsigned int freed = (unsigned int)(p + 1) * pend_stride / 8u;
+                            cb_lim = freed < (unsigned int)CB ? freed : (unsigned int)CB;
                             filter(tv, parked_row0(p));
                         }
-                        direct = false;
+                        cb_lim = CB;
                         npend = 0;
                     }
                     filter(acc, row0_prev);
@@ -986,7 +1004,82 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
 #if HDB_FUSED_STAMPS
     if (tid == 0) hdb_fused_stamps[16 * blockIdx.x + 7] = (unsigned long long)(gp - nA);      // positions generated in phase B
 #endif
-    flush();
+    if (!local) flush();
+    else {
+        // ---- local flavour: every tile of this workgroup is parked.  Wave q: threshold b_w of query q, then its rows ----
+        if (w == 0 && lane == 0) asm volatile("ds_write_b32 %0, %1" :: "v"(ctl_addr + 32u), "v"((unsigned int)npend) : "memory");
+        hdb_lds_barrier();
+        HDB_STAMP(2);
+        if (w < nq) {
+            const int q = w;
+            unsigned int np_u;
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(np_u) : "v"(ctl_addr + 32u) : "memory");
+            const int nvals = __builtin_amdgcn_readfirstlane((int)np_u) * R;
+            const int tstride = (VALU ? VQ : nq) * R;                 // floats per parked tile
+            const float qm = hdb_lds_ld32(qpar_addr + (unsigned int)q * 4u);
+            // this lane's share of the workgroup's scores of query q, in registers: flat index fi = lane + 64 u -> tile fi / R, row fi % R
+            // (plain LDS reads: the stream is over, nothing is in flight that they could drain)
+            constexpr int NI = 16;                                     // 16 tiles x 64 rows / 64 lanes
+            const float* pq = pbuf + q * R;
+            const unsigned long long* prow0 = reinterpret_cast<const unsigned long long*>(tsc);
+            float xs[NI]; uint32_t ks[NI], rws[NI];
+            uint32_t cur = 0u;
+#pragma unroll
+            for (int u = 0; u < NI; ++u) {
+                const int fi = lane + 64 * u;
+                ks[u] = 0u; xs[u] = 0.f; rws[u] = 0u;
+                if (fi < nvals) {
+                    const int p = fi / R, r = fi - p * R;
+                    const float x = pq[p * tstride + r];
+                    const int64_t row = (int64_t)prow0[p] + r;
+                    // key 0: not a candidate (past the last row, or excluded by the row mask)
+                    if (row < n_rows && !(HAS_BIAS && x == -INFINITY)) ks[u] = hdb_f2key(hdb_canon(x));
+                    xs[u] = x; rws[u] = (uint32_t)row;
+                }
+                cur = max(cur, ks[u]);
+            }
+            // the local_m-th largest LANE maximum: at least local_m rows reach it (fewer lanes with rows: 0 = everything goes)
+            uint32_t thr_key = 0u;
+            for (uint32_t r = 0; r < f.local_m; ++r) {
+                const uint32_t v = hdb_wave_max_dpp(cur);
+                thr_key = v;
+                if (v == 0u) break;
+                const unsigned long long who = __ballot(cur == v);
+                if (lane == (int)__ffsll((long long)who) - 1) cur = 0u;
+            }
+            uint32_t cnt = 0u;
+#pragma unroll
+            for (int u = 0; u < NI; ++u) cnt += (uint32_t)__popcll(__ballot(ks[u] != 0u && ks[u] >= thr_key));
+            // slotted lists: this workgroup's own region of the list, no reservation (the last workgroup reads the count below);
+            // fp16 euclidean keeps a compact list (one returning atomic) for the near-duplicate re-score of hdb_finalize_body
+            uint32_t base = (uint32_t)b * f.local_slot;
+            const uint32_t lim = SLOTTED ? base + f.local_slot : f.cap;
+            if constexpr (!SLOTTED) {
+                base = 0u;
+                if (lane == 0 && cnt) base = atomicAdd(&f.ctl[2 + q], cnt);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            }
+            uint32_t run = 0u;
+#pragma unroll
+            for (int u = 0; u < NI; ++u) {
+                const bool pass = ks[u] != 0u && ks[u] >= thr_key;
+                const unsigned long long bal = __ballot(pass);
+                if (pass) {
+                    const uint32_t pos = base + run + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+                    const float sc = hdb_canon((HAS_BIAS || METRIC == 2) ? xs[u] : xs[u] * qm);
+                    if (pos < lim) f.cand[(int64_t)q * f.cap + pos] = hdb_pack(sc, rws[u]);
+                }
+                run += (uint32_t)__popcll(bal);
+            }
+            // b_w as a key of the SCORE domain (what the entries carry): rows this workgroup did not emit score at or below it
+            if (lane == 0) {
+                const float xt = hdb_key2f(thr_key);
+                const uint32_t bkey = thr_key == 0u ? 0u : hdb_f2key(hdb_canon((HAS_BIAS || METRIC == 2) ? xt : xt * qm));
+                __hip_atomic_store((hdb_gu64*)(f.gran + (b * HDB_FUSED_GRAN_PER_WG + q)), ((unsigned long long)cnt << 32) | bkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        HDB_STAMP(3);
+    }
 
     // ---- finish: drain, release, ticket; the last workgroup finalizes every query -------------------
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1029,6 +1122,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
         for (int q = 0; q < nq; ++q) {
             const uint32_t tot0 = __hip_atomic_load(f.ctl + 2 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t tot = aborted ? 0u : tot0;
+            uint32_t tot_eff = tot, ovf_eff = 0u;        // (slotted lists: the sum of the workgroups' counts; a workgroup with more rows than its slot holds = overflow)
             float fm = 1.f, ssq = 0.f;
 #pragma unroll
             for (int qq = 0; qq < HDB_FUSED_MAXQ; ++qq) if (qq == q) { fm = floor_mul[qq]; ssq = qsq_fin[qq]; }
@@ -1064,11 +1158,47 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
                     __syncthreads();
                 }
             };
-            const uint32_t kth_above = hdb_finalize_body(fbuf, f.cand + (int64_t)q * f.cap, tot, q, f.cap, f.k, f.kk, f.row_base, f.idx_out,
-                                                       f.score_out, nullptr, 0, 0, f.thr_out + q, fm, rescore);
+            // local flavour: the floor is the highest b_w of any workgroup (score-domain keys in the granule area)
+            // local flavour: the floor is the highest b_w of any workgroup (score-domain keys in the granule area, with the
+            // workgroups' entry counts: the slotted lists have no counter of their own)
+            uint32_t maxb = 0u, ltot = tot, lovf = 0u;
+            uint32_t* wmb = reinterpret_cast<uint32_t*>(smem + (size_t)HDB_CAND_CAP * 16 + 2048 * 4 + 64);      // [0..7] wave maxima, [8..15] wave sums, [16] overflow, [32 ..] counts per workgroup
+            if (local) {
+                uint32_t bk = 0u, cs = 0u;
+                if (tid == 0) wmb[16] = 0u;
+                for (int64_t wg = tid; wg < G; wg += 512) {
+                    const unsigned long long gw = __hip_atomic_load((hdb_gu64*)(f.gran + (wg * HDB_FUSED_GRAN_PER_WG + q)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t c = (uint32_t)(gw >> 32);
+                    bk = max(bk, (uint32_t)gw);
+                    cs += c < f.local_slot ? c : f.local_slot;
+                    wmb[32 + wg] = c < f.local_slot ? c : f.local_slot;
+                    if (SLOTTED && c > f.local_slot) lovf = 1u;
+                }
+                bk = hdb_wave_max_dpp(bk);
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) cs += (uint32_t)__shfl_xor((int)cs, o, 64);
+                if (lane == 0) { wmb[w] = bk; wmb[8 + w] = cs; }
+                __syncthreads();
+                if (lovf) wmb[16] = 1u;
+                uint32_t sum = 0u;
+#pragma unroll
+                for (int w2 = 0; w2 < 8; ++w2) { maxb = max(maxb, wmb[w2]); sum += wmb[8 + w2]; }
+                if (SLOTTED) ltot = aborted ? 0u : sum;
+                __syncthreads();
+                lovf = wmb[16];
+            }
+            uint32_t kth_above;
+            if constexpr (METRIC == 2 && sizeof(E) == 2)
+                kth_above = hdb_finalize_fast(fbuf, f.cand + (int64_t)q * f.cap, tot, q, f.cap, f.k, f.kk, f.row_base, f.idx_out,
+                                              f.score_out, nullptr, 0, 0, f.thr_out + q, fm, rescore, local, maxb);
+            else
+                kth_above = hdb_finalize_fast(fbuf, f.cand + (int64_t)q * f.cap, ltot, q, f.cap, f.k, f.kk, f.row_base, f.idx_out,
+                                              f.score_out, nullptr, 0, 0, f.thr_out + q, fm, HdbNoFix(), local, maxb,
+                                              local ? wmb + 32 : nullptr, f.local_slot, (uint32_t)G);
+            if (local && SLOTTED) { tot_eff = ltot; ovf_eff = lovf; }
             if (tid == q) {
-                const uint32_t nc = tot < f.cap ? tot : f.cap;
-                my_status = (tot > f.cap ? HDB_Q_OVERFLOW : 0) | ((nc < f.kk || (f.kk > 0 && !kth_above)) ? HDB_Q_UNDERFLOW : 0) | (((qnan_bits >> q) & 1u) ? HDB_Q_NAN : 0);
+                const uint32_t nc = tot_eff < f.cap ? tot_eff : f.cap;
+                my_status = ((tot_eff > f.cap || ovf_eff) ? HDB_Q_OVERFLOW : 0) | ((nc < f.kk || (f.kk > 0 && !kth_above)) ? HDB_Q_UNDERFLOW : 0) | (((qnan_bits >> q) & 1u) ? HDB_Q_NAN : 0);
             }
             __syncthreads();
         }
@@ -1083,7 +1213,7 @@ __global__ __launch_bounds__(512) void hdb_mfma_fused_kernel(ScanArgs a, FusedAr
 
 static size_t fused_lds_bytes(int stage_bytes, size_t pend_bytes) {
     const size_t scan = mfma_lds_bytes(stage_bytes) + 2 * HDB_FUSED_MAXQ * 64 * 4 + 16 * 4 + pend_bytes + 64;
-    const size_t fin = (size_t)HDB_CAND_CAP * 16 + 2048 * 4 + 64;           // hdb_finalize_body in the last workgroup
+    const size_t fin = (size_t)HDB_CAND_CAP * 16 + 2048 * 4 + 64 + 128 + HDB_FUSED_MAX_WG * 4;      // hdb_finalize_body in the last workgroup (+ wave maxima / sums and the workgroups' counts of the local flavour)
     return scan > fin ? scan : fin;
 }
 

@@ -25,6 +25,15 @@ extern "C" int hdb_mfma_fused_supported(int dtype, int d, int metric, int nq, ui
     return shape && (metric == HDB_DOT || metric == HDB_COSINE || metric == HDB_PEARSON || euclid) && nq >= 1 && nq <= maxq && kk <= 128;
 }
 
+// Local flavour (FusedArgs::local, hdb_mfma_fused.h): how many tiles of a workgroup fit its parking area -- 0 where the kernel
+// does not park at all (fp16 d = 768; euclidean d = 640: the parking state would spill there).  Mirrors PARK / pend_max.
+extern "C" int hdb_mfma_fused_local_tiles(int dtype, int d, int metric, int nq) {
+    if (dtype == HDB_F32) return nq <= 1 || d > 384 ? 16 : 8;
+    const bool park = (d <= 640 && !(metric == HDB_EUCLIDEAN && d > 512)) || d > 768;
+    if (!park) return 0;
+    return nq <= 2 ? 16 : 32 / nq;
+}
+
 // bytes of the persistent control block: 64 words of counters + the granules
 extern "C" size_t hdb_mfma_fused_ctl_bytes(void) { return HDB_FUSED_HDR_BYTES + (size_t)HDB_FUSED_MAX_WG * HDB_FUSED_GRAN_PER_WG * 8; }
 

@@ -119,13 +119,25 @@ class GpuGroup:
             raise ValueError(f"operands could not be broadcast together with shapes ({self.n},) ({a.shape[0]},)")
         return [a[lo:hi] for lo, hi in self.bounds]
 
+    def _settle(self):
+        """Per-row inputs are produced on torch's current stream of each shard's device (uploads, the decay kernel); the
+        group's workers query on private non-blocking streams that do not order against it.  Called once per set_* with
+        data, never per query."""
+        for s in self.shards:
+            if s.n:
+                torch.cuda.current_stream(s.device).synchronize()
+
     def set_bias(self, bias):
         for s, part in zip(self.shards, [None] * len(self.shards) if bias is None else self._split(bias)):
             s.set_bias(part)
+        if bias is not None:
+            self._settle()
 
     def set_row_mask(self, mask):
         for s, part in zip(self.shards, [None] * len(self.shards) if mask is None else self._split(mask)):
             s.set_row_mask(part)
+        if mask is not None:
+            self._settle()
 
     def set_recency(self, timestamps, recency_bias, ts_max=None, valid=None):
         """The maximum of reference ranking_algorithm.py:183 is over ALL rows: computed once here, passed to every shard."""
@@ -141,6 +153,7 @@ class GpuGroup:
         for s, (lo, hi) in zip(self.shards, self.bounds):
             if s.n:
                 s.set_recency(ts[lo:hi], recency_bias, ts_max=ts_max)
+        self._settle()
 
     def set_option(self, name, value):
         for s in self.shards:

@@ -220,8 +220,13 @@ class HyperDB:
         if not drop:
             return
         gone = set(drop)
+        drops_a_nan = False
         if self._index is not None:
-            self._dead = np.union1d(self._dead, self._live_rows()[np.asarray(drop, dtype=np.int64)])
+            dropped_rows = self._live_rows()[np.asarray(drop, dtype=np.int64)]
+            # only a removal that takes a NaN row away can clear the matrix's NaN flag: look at the dropped rows themselves
+            # (O(dropped x d) on the device) instead of compacting the whole matrix on every removal while the flag is up
+            drops_a_nan = self._index.has_nan and self._rows_have_nan(dropped_rows)
+            self._dead = np.union1d(self._dead, dropped_rows)
         self.documents = [d for i, d in enumerate(self.documents) if i not in gone]
         kept_src = [s_ for s_ in self.source_indices if s_ not in gone]     # :737-745
         drop_arr = np.asarray(drop)
@@ -232,11 +237,27 @@ class HyperDB:
         if not self.documents:
             self._index.close()
             self._index, self._dead = None, np.zeros(0, dtype=np.int64)
-        elif self._dead.size * 4 > self._index.n or self._index.has_nan:
+        elif self._dead.size * 4 > self._index.n or drops_a_nan:
             # (a stored NaN: the library's flag covers tombstoned rows too, and the reference answers normally as soon as the
             # NaN document is gone -- compact at once, the gather recomputes the flag over the rows it keeps)
             self._index.compact(self._live_rows())
             self._dead = np.zeros(0, dtype=np.int64)
+
+    def _rows_have_nan(self, rows):
+        """Does any of the device rows `rows` hold a NaN?  (lifecycle helper of remove_document, not on the query path)"""
+        rows = np.asarray(rows, dtype=np.int64)
+        for sh, lo, hi in self._shards():
+            mine = rows[(rows >= lo) & (rows < hi)] - lo
+            if mine.size and bool(torch.isnan(sh.V[torch.from_numpy(mine).to(sh.device)]).any().item()):
+                return True
+        return False
+
+    def invalidate_rows(self):
+        """Call after mutating stored documents IN PLACE (metadata values, timestamps): the device row masks of filters and
+        the recency biases are cached per filter / (key, filter, recency_bias) until the document list changes through
+        add / remove_document, whereas the reference re-evaluates filters and timestamps on every uncached query
+        (hyperdb.py:1492-1493, :1555).  Also clears the LRU query cache, as add / remove do (:566, :766)."""
+        self._invalidate_rows()
 
     @property
     def vectors(self):
@@ -554,6 +575,11 @@ class HyperDB:
         t_max, t_min = float(np.max(kept)), float(np.min(kept))
         hit = [sh.recency_twice(cols[p], None if masks is None else masks[p], recency_bias, t_max, t_min) if sh.n else None
                for p, (sh, lo, hi) in enumerate(self._shards())]
+        # The decay kernels run on torch's current stream of each shard's device; a shard group (devices=[...]) queries on
+        # private non-blocking streams that do not order against it.  Once per cache miss, never per query: wait here.
+        for sh, lo, hi in self._shards():
+            if sh.n:
+                torch.cuda.current_stream(sh.device).synchronize()
         self._bias_cache[bkey] = hit
         while len(self._bias_cache) > self._ROW_CACHE_SLOTS:
             self._bias_cache.popitem(last=False)

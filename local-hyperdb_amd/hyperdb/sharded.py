@@ -161,6 +161,11 @@ class HipEngine:
 
     def merge_packed_into(self, gathered, parts, nq, k, out_record):
         from . import _native
+        if parts * k > _native.MERGE_DEVICE_CAP:                  # (see merge_packed_to_host)
+            out = np.empty(_native.packed_bytes(nq, k), dtype=np.uint8)
+            _native.merge_topk_host(gathered.cpu().numpy(), parts, nq, k, out)
+            out_record.copy_(torch.from_numpy(out))
+            return
         _native.merge_topk_packed_into(gathered, parts, nq, k, out_record)
 
     def record_to_host(self, record, nq, k):
@@ -186,9 +191,14 @@ class HipEngine:
             host = self._host[("merge", nb)] = torch.empty(nb, dtype=torch.uint8, pin_memory=True)
             while len(self._host) > _native.HOST_RECORD_SLOTS:
                 self._host.popitem(last=False)
-        _native.merge_topk_packed_into(gathered, parts, nq, k, host)
-        torch.cuda.current_stream(self.device).synchronize()
         h = host.numpy()
+        if parts * k > _native.MERGE_DEVICE_CAP:
+            # the merge kernel ranks parts*k entries per query in LDS (<= 8192): beyond that the gathered records come to the
+            # host in one copy and hdb_merge_topk_host (any parts*k) merges them -- the transport stays the all-gather
+            _native.merge_topk_host(gathered.cpu().numpy(), parts, nq, k, h)
+        else:
+            _native.merge_topk_packed_into(gathered, parts, nq, k, host)
+            torch.cuda.current_stream(self.device).synchronize()
         return (h[:nq * k * 8].view(np.int64).reshape(nq, k), h[nq * k * 8:nq * k * 12].view(np.float32).reshape(nq, k),
                 h[nq * k * 12:nq * k * 12 + nq * 4].view(np.int32))
 
@@ -231,6 +241,7 @@ class ShardedIndex:
         self.n_total = n_total
         self.force_exchange = force_exchange and group is not None     # run gather+merge even with one rank (tests)
         self._hx = None
+        self._host_out = {}               # (nq, k) -> merged record of the host-side merge of an all-gather (world*k > 8192)
         # default: the RCCL all-gather (what the north star names).  The shared-memory swap is chosen explicitly -- exchange="host" /
         # HDB_EXCHANGE=host -- or by a caller that has timed both on its node (bench.py calibrates and reports both); "auto" =
         # the swap wherever every rank sits on one node.
@@ -301,14 +312,29 @@ class ShardedIndex:
             except Exception as e:                               # noqa: BLE001
                 err = e
                 if self.world > 1 or self.force_exchange:
-                    rec.copy_(torch.from_numpy(self._poison_record(nb, nq, k)))
+                    # (a sticky device error makes this copy raise too: the rank can then not reach the exchange at all)
+                    try:
+                        rec.copy_(torch.from_numpy(self._poison_record(nb, nq, k)))
+                    except Exception as e2:                      # noqa: BLE001
+                        self._leave_group(e, e2)
+                        raise e
             if self.world == 1 and not self.force_exchange:
                 if err is not None:
                     raise err
                 return eng.record_to_host(rec, nq, k)           # already the global answer
-            gathered = eng.new_record(nb * self.world, 1)
-            dist.all_gather_into_tensor(gathered, rec, group=self.group)
-            if hasattr(eng, "merge_packed_to_host"):
+            try:
+                gathered = eng.new_record(nb * self.world, 1)
+                dist.all_gather_into_tensor(gathered, rec, group=self.group)
+            except Exception as e2:                              # noqa: BLE001
+                if err is None:
+                    raise
+                self._leave_group(err, e2)
+                raise err
+            if self.world * k > self._merge_device_cap():
+                # the device merge ranks world*k entries per query in LDS (<= 8192; 8 ranks: k <= 1024).  Larger results keep the
+                # same transport -- the all-gather above -- and merge on the host (hdb_merge_topk_host: any world*k)
+                out = self._merge_gathered_on_host(gathered, nq, k)
+            elif hasattr(eng, "merge_packed_to_host"):
                 out = eng.merge_packed_to_host(gathered, self.world, nq, k)
             else:
                 merged = eng.new_record(nb, 2)
@@ -319,6 +345,39 @@ class ShardedIndex:
         if (out[2] & self.POISON).any():
             raise RuntimeError("another rank failed while computing its shard's top-k (see that rank's error)")
         return out
+
+    @staticmethod
+    def _merge_device_cap():
+        from . import _native
+        return _native.MERGE_DEVICE_CAP
+
+    def _merge_gathered_on_host(self, gathered, nq, k):
+        """All-gathered packed records (one uint8 tensor, device or host) -> views of the merged record, merged by
+        hdb_merge_topk_host: one D2H copy of world * record bytes, then host code."""
+        from . import _native
+        g = gathered.cpu().numpy()
+        out = self._host_out.get((nq, k))
+        if out is None:
+            if len(self._host_out) >= _native.HOST_RECORD_SLOTS:
+                self._host_out.clear()
+            out = self._host_out[(nq, k)] = np.empty(_native.packed_bytes(nq, k), dtype=np.uint8)
+        return _native.merge_topk_host(g, self.world, nq, k, out)
+
+    def _leave_group(self, err, err2):
+        """This rank's top-k raised AND it cannot publish a poison record (the device is gone): its peers are, or soon will be,
+        inside the collective of this query and would wait for it until the backend's timeout.  Abort the communicator where
+        torch offers that, else end the process with a non-zero code -- under torchrun either one ends the peers' wait."""
+        import os
+        import sys
+        print(f"hyperdb.sharded: rank {self.rank} cannot take part in the exchange any more ({err!r}; then {err2!r}); "
+              "leaving the process group so that the other ranks do not wait", file=sys.stderr, flush=True)
+        abort = getattr(getattr(dist, "distributed_c10d", None), "_abort_process_group", None)
+        try:
+            if abort is None:
+                raise RuntimeError("no abort entry point")
+            abort(self.group)
+        except Exception:                                        # noqa: BLE001
+            os._exit(70)
 
     # -- public --------------------------------------------------------------------------------
     def set_recency(self, timestamps, recency_bias):

@@ -299,3 +299,87 @@ def test_a_failing_rank_poisons_the_exchange_instead_of_hanging_it(tmp_path, exc
     r1 = open(tmp_path / "rank1.txt").read().split("|")
     assert r1[0] == "ValueError:shard exploded" and r0[0].startswith("RuntimeError:another rank failed")
     assert r0[1] == "1" and r1[1] == "1"
+
+
+def _bigk_worker(rank, world, port, out_dir, exchange, nq):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "local-hyperdb_amd"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from hyperdb.sharded import ShardedIndex, shard_bounds
+        rng = np.random.default_rng(123)
+        n, d, k = 4000, 8, 3000
+        V = rng.standard_normal((n, d)).astype(np.float32)
+        V[2100] = V[7]                                     # a tie across shards
+        Q = torch.from_numpy(rng.standard_normal((nq, d)).astype(np.float32))
+        lo, hi = shard_bounds(n, world, granule=16)[rank]
+
+        class NoDeviceMerge(OracleEngine):
+            """The device merge kernels rank at most 8192 entries per query: the product path must never ask for more."""
+
+            def merge_packed_into(self, gathered, parts, nq_, k_, out_record):
+                assert parts * k_ <= 8192, "world*k above the device merge's cap reached the device merge"
+                return super().merge_packed_into(gathered, parts, nq_, k_, out_record)
+        eng = NoDeviceMerge(V[lo:hi], lo)
+        sh = ShardedIndex(None, n_total=n, group=dist.group.WORLD, engine=eng, exchange=exchange)
+        idx, sc = sh.query(Q, k, 1)                        # every shard holds < k rows: its record is padded with -1
+        i2, s2 = sh.query(Q, k, 1)
+        assert np.array_equal(idx, i2) and np.array_equal(sc, s2)
+        small_i, _ = sh.query(Q, 10, 1)                    # world*k = 80: the device-merge branch still serves small k
+        assert np.array_equal(small_i, idx[:, :10])
+        used_host_swap = sh._hx is not None and eng.packed_bytes(nq, k) <= sh._hx.slot_bytes
+        sh.close()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), idx=idx, sc=sc, swap=used_host_swap)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange,nq", [("collective", 2), ("host", 1), ("host", 6)])
+def test_eight_ranks_k_3000_merges_on_the_host(tmp_path, exchange, nq):
+    """8 ranks x k = 3000 = 24 000 entries per query exceeds what the device merge ranks in LDS (8192).  The
+    all-gather path now merges the gathered records with hdb_merge_topk_host; the shared-memory swap always did (one query: the
+    36-KB record fits a slot; six queries: 216 KB does not, so that call takes the all-gather and the host merge)."""
+    from oracle import ranking_oracle as orc
+    world, n, d, k = 8, 4000, 8, 3000
+    port = 39500 + (os.getpid() % 2000) + (10 if exchange == "host" else 0) + nq
+    mp.spawn(_bigk_worker, args=(world, port, str(tmp_path), exchange, nq), nprocs=world, join=True)
+    rng = np.random.default_rng(123)
+    V = rng.standard_normal((n, d)).astype(np.float32)
+    V[2100] = V[7]
+    Q = rng.standard_normal((nq, d)).astype(np.float32)
+    ranks = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    assert bool(ranks[0]["swap"]) == (exchange == "host" and nq == 1)
+    for r in ranks[1:]:
+        assert np.array_equal(r["idx"], ranks[0]["idx"]) and np.array_equal(r["sc"], ranks[0]["sc"])
+    for qi in range(nq):
+        ex = orc.exact_scores(V, Q[qi], METRICS[1]).astype(np.float32)
+        want = np.lexsort((np.arange(n), -ex))[:k]
+        assert np.array_equal(ranks[0]["idx"][qi], want) and np.array_equal(ranks[0]["sc"][qi], ex[want])
+
+
+def test_a_rank_that_cannot_publish_leaves_the_group(monkeypatch):
+    """when the local top-k raised AND the poison record cannot be written (a sticky device error), the rank must not
+    simply re-raise -- its peers are on their way into the collective.  _gather_merge calls _leave_group (abort the
+    communicator / exit non-zero) before re-raising the ORIGINAL error."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "local-hyperdb_amd"))
+    from hyperdb.sharded import ShardedIndex
+
+    class Dead(OracleEngine):
+        def topk_packed(self, Q_, k_, metric_id, record, exact=False):
+            raise ValueError("device lost")
+
+        def new_record(self, nbytes, slot=0):
+            class Rec:                                       # a record whose upload fails like the kernels did
+                def copy_(self_inner, _src):
+                    raise RuntimeError("hipErrorLaunchFailure")
+            return Rec()
+    sh = ShardedIndex(None, n_total=10, group=None, engine=Dead(np.zeros((10, 4), dtype=np.float32), 0))
+    sh.world, sh.force_exchange = 2, True                    # as if a second rank were waiting
+    left = []
+    monkeypatch.setattr(sh, "_leave_group", lambda e1, e2: left.append((str(e1), str(e2))))
+    with pytest.raises(ValueError, match="device lost"):
+        sh._gather_merge(torch.zeros((1, 4)), 3, 1, exact=False)
+    assert left == [("device lost", "hipErrorLaunchFailure")]
