@@ -190,6 +190,12 @@ def extra_leg(name, device):
     alg = n * d * elem
     if metric == "hamming_distance":
         alg = n * ((d + 31) // 32) * 4              # packed sign bits, word-major: what the scan reads (one-time pack excluded)
+    traffic = None
+    try:                                                     # HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/hbm_traffic.json)
+        tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+        traffic = tj.get(f"n={n},d={d},{'fp32' if elem == 4 else 'fp16'},q={q},{metric}", {}).get("hbm_bytes_per_launch")
+    except Exception:
+        traffic = None
     fused = ix.stat("fused")
     kernel = {1: "hdb_mfma_fused_kernel", 2: "hdb_mfma_kernel MODE 2", 3: "hdb_bits_fused_kernel"}.get(fused, "hdb_mfma_kernel / hdb_scan_kernel filter pass")
     out = {"config": name, "workload": f"N={n} d={d} {'fp32' if elem == 4 else 'fp16'} Q={q} {metric}{' + recency bias' if bias else ''} top-100",
@@ -197,7 +203,7 @@ def extra_leg(name, device):
            "kernel": kernel + (" (single launch: the whole call)" if fused else ""), "launches_timed": nl,
            "kernel_us": kern_s * 1e6, "mfma_path": bool(ix.stat("mfma")), "single_launch": bool(fused),
            "roofline": {"bound": "hbm", "achieved": alg / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": alg / kern_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg}}
+                        "frac": alg / kern_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg}}
     ix.close()
     del V
     torch.cuda.empty_cache()

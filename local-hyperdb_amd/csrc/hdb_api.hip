@@ -52,6 +52,7 @@ int hdb_launch_mfma_scan(const ScanArgs* args, int dtype, int mode, int nq_launc
                          const float* qsq, const float* qscl, int max_blocks, int variant, void* stream, const BatchArgs* f);
 int hdb_mfma_batch_capacity(int dtype, int d);
 int hdb_mfma_ksplit_slices(int dtype, int d);
+int hdb_mfma_anyd_pad(int dtype, int d);
 int hdb_l1_tile_supported(int dtype, int d);
 int hdb_launch_l1_tile(const ScanArgs* args, int dtype, int mode, int nq_launch, int max_blocks, void* stream);
 int hdb_bits_fused_supported(int metric, int nq, int W, uint32_t kk);
@@ -147,7 +148,9 @@ struct hdb_index {
     int64_t use_fused = 1;            // 1-4 dot / cosine queries on an fp16 matrix: the whole call in ONE kernel (hdb_mfma_fused.h)
     int64_t use_local = 1;            // ... short matrices: its local flavour (no row sample, no exchange; every workgroup its own threshold)
     int64_t local_m = 0;              // ... rows every workgroup emits at least (0 = automatic: ~3072 / workgroups, 8 .. 32)
-    int64_t local_max_q = 2;          // ... for calls of up to this many queries (three and four: the batched single launch is faster, profiles/r4_latency_map.txt)
+    int64_t local_max_tiles = 4;      // ... while a workgroup has at most this many tiles (the parking area holds 16)
+    int64_t local_small = 0;          // ... 1: also for matrices of up to 8192 rows (measured slower than the three launches)
+    int64_t local_max_q = 1;          // ... for calls of up to this many queries (two to four: the batched single launch is faster -- 36 vs 45 us at 20k rows, profiles/r4_latency_map.txt)
     int64_t use_l1_tile = 1;          // manhattan: dense passes through the LDS-staged tile kernel (hdb_l1_tile.hip)
     int64_t use_batch1 = 1;           // 5+ queries (euclidean: 1+) on the matrix cores, k <= 128: the whole call in ONE launch per <= 256 queries (needs use_fused)
     int64_t fused_timeout_us = 2000;  // bound of every in-kernel spin of those kernels
@@ -364,6 +367,8 @@ extern "C" int hdb_set_option(hdb_index* ix, const char* name, int64_t value) {
     else if (!strcmp(name, "use_batch1")) ix->use_batch1 = value;
     else if (!strcmp(name, "use_local")) ix->use_local = value;
     else if (!strcmp(name, "local_max_q")) ix->local_max_q = value;
+    else if (!strcmp(name, "local_max_tiles")) ix->local_max_tiles = std::max<int64_t>(1, value);
+    else if (!strcmp(name, "local_small")) ix->local_small = value;
     else if (!strcmp(name, "local_m")) ix->local_m = std::max<int64_t>(0, std::min<int64_t>(value, 64));
     else if (!strcmp(name, "use_l1_tile")) ix->use_l1_tile = value;
     else if (!strcmp(name, "host_poll")) ix->host_poll = value;
@@ -596,7 +601,8 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     // rows of up to 384 elements are faster through the batched single launch from ~300k rows on (n = 2M x 384: 595 / 640 -> 510 us;
     // d = 768: 1 030 vs 1 714, the VALU pass stays)
     const int64_t f32_min_q = ix->f32_min_q >= 0 ? ix->f32_min_q : ((ix->d <= 384 && n >= 300000) ? 3 : 5);
-    const int64_t min_q = hdb_mfma_ksplit_slices(ix->dtype, ix->d) > 0 ? std::max<int64_t>(ix->mfma_min_q, 5)
+    // (widths without a geometry of their own ride the next wider one through the multi-kernel pipeline: like the K slices, from five queries on)
+    const int64_t min_q = (hdb_mfma_ksplit_slices(ix->dtype, ix->d) > 0 || hdb_mfma_anyd_pad(ix->dtype, ix->d) > 0) ? std::max<int64_t>(ix->mfma_min_q, 5)
                         : ix->dtype == HDB_F32 ? std::max<int64_t>(ix->mfma_min_q, f32_min_q) : ix->mfma_min_q;
     // hdb_mfma_fused_kernel is built around ONE multiplying wave and two selector waves: with 2-4 fp16 queries its sample phase and
     // epilogue cost more than the batched single launch (eight multiplying waves) until the pass itself dominates -- n = 100k x 384,
@@ -610,14 +616,16 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     // float32 in the VALU from the same staged tiles)
     // Short matrices: the single launch in its LOCAL flavour -- no row sample, no exchange; every workgroup parks the scores of all
     // its tiles and emits the rows at or above its own local_m-th best (hdb_mfma_fused.h).  Possible while a workgroup's tiles fit
-    // its parking area (fp16 d = 384: 16 tiles of 64 rows on 256 CUs = 262 144 rows); it also serves the matrices of up to 8192 rows
-    // the three-launch pipeline used to take (the reference's own sizes: 151 and 10 000 documents, tests/perf_hyperdb.py:15).
+    // its parking area (up to 16); used, by measurement (profiles/r4_latency_map.txt, same box, interleaved), up to local_max_tiles =
+    // 4 tiles per workgroup (fp16 d = 384: 65 536 rows): 35 vs 37 us at 20k rows, 45 vs 45 at 100k, 62 vs 59 at 250k -- beyond that
+    // the exchange flavour filters while it streams and the local one selects after its last tile.  Matrices of up to 8192 rows keep
+    // the three launches (thr = -inf, scan, finalize): 26 us at 1000 rows against 31 for this kernel's launch ramp and last workgroup.
     const int fl_rows = hdb_mfma_tile_rows(ix->dtype, ix->d);
     const int64_t fl_tiles = fl_rows > 0 ? (n + fl_rows - 1) / fl_rows : 0;
     int64_t fl_grid = std::min<int64_t>(fl_tiles, hdb_cu_count());
     if (ix->max_blocks > 0) fl_grid = std::min<int64_t>(fl_grid, ix->max_blocks);
     const int fl_cap = fl_rows > 0 && nq >= 1 && nq <= HDB_FUSED_MAXQ_RULE && nq <= ix->local_max_q ? hdb_mfma_fused_local_tiles(ix->dtype, ix->d, metric, nq) : 0;
-    const bool local_ok = fl_grid * 32 <= HDB_CAND_CAP && ix->use_fused && ix->use_local && !ix->force_exact && !exact_req && (ix->dtype == HDB_F32 || (ix->use_mfma && nq >= ix->mfma_min_q)) && fl_grid > 0 && fl_cap > 0 && (fl_tiles + fl_grid - 1) / fl_grid <= fl_cap &&
+    const bool local_ok = fl_grid * 32 <= HDB_CAND_CAP && ix->use_fused && ix->use_local && !ix->force_exact && !exact_req && (ix->dtype == HDB_F32 || (ix->use_mfma && nq >= ix->mfma_min_q)) && fl_grid > 0 && fl_cap > 0 && (fl_tiles + fl_grid - 1) / fl_grid <= std::min<int64_t>(fl_cap, ix->local_max_tiles) && (!small || ix->local_small) &&
                           !is_ham && kk <= 128 && dev_status != nullptr && hdb_mfma_fused_supported(ix->dtype, ix->d, metric, nq, kk);
     if (local_ok) exact = false;                       // (k a large share of the rows: every workgroup then emits all its rows)
     const bool fused_shape = ix->use_fused && !exact && (!small || local_ok) && k <= HDB_MAX_K && dev_status != nullptr && !is_ham &&

@@ -77,10 +77,14 @@ typedef __attribute__((address_space(1))) unsigned long long hdb_bgu64;
 
 // The eight largest of the (up to two, a >= b) keys every thread brings: each wave extracts its eight largest (DPP maxima),
 // wave 0 the eight largest of those.  Returns, in lane r < 8 of wave 0, the r-th largest (0 elsewhere).  scratch: waves x 8 words.
+// PW < 8: every wave brings only its PW largest -- the result is then the 8-th largest of those, a LOWER BOUND of the true 8-th
+// largest (all a threshold needs) at a fraction of the extraction rounds.
+template <int PW = 8>
 __device__ __forceinline__ uint32_t hdb_wg_top8(uint32_t a, uint32_t b, uint32_t* scratch) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (PW < 8 && lane < 8) scratch[w * 8 + lane] = 0u;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < PW; ++r) {
         const uint32_t v = hdb_wave_max_dpp(a);
         const unsigned long long who = __ballot(a == v);
         if (lane == (int)__ffsll((long long)who) - 1) { a = b; b = 0u; }
@@ -338,7 +342,7 @@ __global__ __launch_bounds__(HDB_BITS_THREADS) void hdb_bits_fused_kernel(BitsAr
                     const uint32_t lo = min(t0, key);
                     t0 = max(t0, key); t1 = max(t1, lo);
                 }
-                const uint32_t r8 = hdb_wg_top8(t0, t1, scratch);
+                const uint32_t r8 = hdb_wg_top8<3>(t0, t1, scratch);
                 if (w == 0 && lane == 7) xthr[qq] = r8 ? hdb_key2f(r8) : -INFINITY;
             }
         }
@@ -405,16 +409,29 @@ __global__ __launch_bounds__(HDB_BITS_THREADS) void hdb_bits_fused_kernel(BitsAr
     for (int qq = 0; qq < QH; ++qq) {
         if (qq < nq) {
             const uint32_t have = min(lcnt[qq], LCAP);
-            if (local) {
+            if (local && have <= 24u) {
+                // a short list goes out as it is: everything at or above the FIRST threshold b0 was collected, so b0 is this workgroup's b_w
+                if (tid == 0) {
+                    xflag[14] = have ? atomicAdd(&gcnt[qq], have) : 0u;
+                    __hip_atomic_store((hdb_bgu64*)(reinterpret_cast<char*>(a.ctl) + HDB_BATCH_GRAN_BYTE + ((int64_t)qq * G + b) * 64),
+                                       (unsigned long long)(thr[qq] == -INFINITY ? 0u : hdb_f2key(thr[qq])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+                const uint32_t base = xflag[14];
+                for (uint32_t e = tid; e < have; e += HDB_BITS_THREADS)
+                    if (base + e < a.cap) a.cand[(int64_t)qq * a.cap + base + e] = lbuf[(uint32_t)qq * LCAP + e];
+                __syncthreads();
+            } else if (local) {
                 // b_w = the 8-th best of what this workgroup collected (every thread brings the two best of its share of the list;
                 // a list longer than two entries per thread makes it a lower bound of the 8-th best, which is all the check needs)
+                // (entry e goes to wave e mod 16: a list of a hundred entries must reach every wave, each of which brings three)
                 uint32_t t0 = 0u, t1 = 0u;
-                for (uint32_t e = tid; e < have; e += HDB_BITS_THREADS) {
+                for (uint32_t e = (uint32_t)w + (uint32_t)HDB_BITS_WAVES * (uint32_t)lane; e < have; e += HDB_BITS_THREADS) {
                     const uint32_t key = (uint32_t)(lbuf[(uint32_t)qq * LCAP + e] >> 32);
                     const uint32_t lo = min(t0, key);
                     t0 = max(t0, key); t1 = max(t1, lo);
                 }
-                const uint32_t r8 = hdb_wg_top8(t0, t1, scratch);
+                const uint32_t r8 = hdb_wg_top8<3>(t0, t1, scratch);
                 if (tid == 7) { xflag[14] = r8; xflag[15] = 0u; }       // (lane 7 of wave 0: the 8-th largest; 0 = fewer than eight: everything goes)
                 __syncthreads();
                 const uint32_t bkey = xflag[14];
@@ -461,8 +478,10 @@ __global__ __launch_bounds__(HDB_BITS_THREADS) void hdb_bits_fused_kernel(BitsAr
         HDB_XSTAMP(10);
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         bool all_in = true;
-        while ((HDB_BITS_POLL ? __hip_atomic_fetch_or(a.ctl + HDB_BATCH_CTL_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                              : __hip_atomic_load(a.ctl + HDB_BATCH_CTL_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (unsigned int)G) {
+        // Only the owners of a query (workgroups 0 .. nq-1) wait for everybody: the others have nothing left to do, and 256 pollers
+        // on the line of the arrival counter delayed the arrivals themselves by ~6 us (profiles/r4_bits_timeline.txt)
+        while ((int64_t)b < (int64_t)nq && ((HDB_BITS_POLL ? __hip_atomic_fetch_or(a.ctl + HDB_BATCH_CTL_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                              : __hip_atomic_load(a.ctl + HDB_BATCH_CTL_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < (unsigned int)G)) {
             if (expired(t0)) { all_in = false; break; }
             __builtin_amdgcn_s_sleep(8);
         }
@@ -494,7 +513,7 @@ __global__ __launch_bounds__(HDB_BITS_THREADS) void hdb_bits_fused_kernel(BitsAr
             __syncthreads();
         }
         hdb_finalize_fast(fbuf, a.cand + (int64_t)q * a.cap, aborted ? 0u : tot0, q, a.cap, a.k, a.kk, a.row_base, a.idx_out, a.score_out,
-                          a.status, qn, 0, nullptr, 1.f, HdbNoFix(), local, floor_key);
+                          a.status, qn, 0, nullptr, 1.f, HdbNoFix(), local, floor_key, nullptr, 0u, 0u, JACCARD ? 2 : 1);
         __syncthreads();
     }
     __syncthreads();

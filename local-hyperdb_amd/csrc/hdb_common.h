@@ -47,6 +47,9 @@ struct ScanArgs {
     // `ks_bytes`-wide pieces of the rows at byte offset ks_off (row pitch ks_pitch, query pitch ks_dfull elements), starts its
     // accumulators from ks_partial_in (nullptr: zero) and, in MODE 3, stores the raw sums to ks_partial_out ([query][ks_ld])
     int64_t ks_pitch; int32_t ks_off; int32_t ks_dfull;
+    int32_t ks_valid;       // bytes of this slice that exist in the row (0 = all of it).  Rows of ANY width that is a multiple of 16 bytes ride the
+                            // geometry of the next multiple of 256 bytes (hdb_mfma_anyd_*.hip): chunks past the end of a row are not fetched
+                            // (the staging re-reads chunk 0 instead) and the query fragments are zero there, so they add nothing
     const float* ks_partial_in; float* ks_partial_out; int64_t ks_ld;
 };
 

@@ -200,7 +200,8 @@ __device__ __forceinline__ uint32_t hdb_finalize_fast(unsigned long long* buf, c
                                                       int64_t* idx_out, float* score_out, int32_t* status, int qnan_flag,
                                                       int32_t extra_status, const float* floor_ptr = nullptr, float floor_mul = 1.f,
                                                       const Fix& fix = Fix(), bool have_floor_key = false, uint32_t floor_key_in = 0u,
-                                                      const uint32_t* slot_cnt = nullptr, uint32_t slot_size = 0u, uint32_t slot_wgs = 0u) {
+                                                      const uint32_t* slot_cnt = nullptr, uint32_t slot_size = 0u, uint32_t slot_wgs = 0u,
+                                                      int max_passes = 4 /* 1: coarse scores (bit metrics) -- a crowded bin is a tie, narrowing the window cannot split it */) {
     // Slotted lists (the local flavour of hdb_mfma_fused.h): workgroup w left slot_cnt[w] (LDS) entries at cand[w * slot_size ...];
     // `total` is their sum.  Such a list is only ever read here (it is not compact: hdb_finalize_body cannot take it), so this path
     // serves every size of it; ties too massive for the survivor list come back as "k-th best not above the floor" (0).
@@ -249,32 +250,55 @@ __device__ __forceinline__ uint32_t hdb_finalize_fast(unsigned long long* buf, c
     HDB_FIN_STAMP(9);
     for (int w2 = 0; w2 < nw; ++w2) { kmin = min(kmin, wred[w2]); kmax = max(kmax, wred[16 + w2]); }
     if (kmin > kmax) { kmin = 0u; kmax = 0u; }       // (an empty list)
-    const uint32_t range = kmax - kmin;
-    const int bits = range ? 32 - __clz((int)range) : 0;
-    const int sh = bits > 10 ? bits - 10 : 0;
-#pragma unroll
-    for (int j = 0; j < NE; ++j)
-        if (ev[j]) atomicAdd(&hist[((uint32_t)(e[j] >> 32) - kmin) >> sh], 1u);
-    __syncthreads();
-    if (wave == 0) {                                 // bins from the top: lane l owns bins NB-1-16l .. NB-16-16l
-        uint32_t loc[16], tot = 0u;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { loc[j] = hist[NB - 1 - (16 * lane + j)]; tot += loc[j]; }
-        uint32_t incl = tot;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
-        uint32_t before = incl - tot;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if (before < kk && kk <= before + loc[j]) ctl[2] = NB - 1 - (uint32_t)(16 * lane + j);      // the bin holding the kk-th largest (none: fewer than kk entries, bin 0 = everything)
-            before += loc[j];
+    // Shift bins over the key window [lo, hi]; when the bin of the kk-th largest is crowded the window shrinks to that bin and the
+    // pass repeats (at most three times: 10 bits per pass).  Orderable keys are far apart around zero -- scores of -0.5 and +0.5 sit
+    // 2^31 keys apart -- so one pass over a list that straddles zero puts all the large scores into a dozen bins (found with the
+    // local flavour at local_m = 24 of 64 rows: thresholds below zero, 300+ entries in the bin of the k-th, round 4).
+    uint32_t lo = kmin, hi = kmax, need = kk, cutoff = kmin;
+#pragma unroll 1
+    for (int pass = 0; pass < max_passes; ++pass) {
+        const uint32_t range = hi - lo;
+        const int bits = range ? 32 - __clz((int)range) : 0;
+        const int sh = bits > 10 ? bits - 10 : 0;
+        if (pass > 0) {
+            for (uint32_t i = tid; i < NB; i += nth) hist[i] = 0u;
+            if (tid == 0) { ctl[2] = 0u; ctl[4] = 0u; ctl[5] = 0u; }
+            __syncthreads();
         }
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            const uint32_t kx = (uint32_t)(e[j] >> 32);
+            if (ev[j] && kx >= lo && kx <= hi) atomicAdd(&hist[(kx - lo) >> sh], 1u);
+        }
+        __syncthreads();
+        if (wave == 0) {                             // bins from the top: lane l owns bins NB-1-16l .. NB-16-16l
+            uint32_t loc[16], tot = 0u;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { loc[j] = hist[NB - 1 - (16 * lane + j)]; tot += loc[j]; }
+            uint32_t incl = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+            uint32_t before = incl - tot;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (before < need && need <= before + loc[j]) {      // the bin holding the wanted entry (none: fewer entries than that, bin 0 = everything)
+                    ctl[2] = NB - 1 - (uint32_t)(16 * lane + j); ctl[4] = before; ctl[5] = loc[j];
+                }
+                before += loc[j];
+            }
+        }
+        __syncthreads();
+        const uint32_t bsel = ctl[2], above = ctl[4], inbin = ctl[5];
+        cutoff = lo + (bsel << sh);
+        if (sh == 0 || inbin <= 48u || pass + 1 >= max_passes) break;          // few enough around the kk-th (or single keys: only ties are left)
+        need -= above;                               // the wanted entry is the need-th largest inside the bin
+        const uint32_t top = cutoff + ((1u << sh) - 1u);
+        lo = cutoff; hi = top < hi ? top : hi;
+        __syncthreads();                             // (everybody has read ctl before the next pass clears it)
     }
-    __syncthreads();
-    const uint32_t bsel = ctl[2];
 #pragma unroll
     for (int j = 0; j < NE; ++j)
-        if (ev[j] && (((uint32_t)(e[j] >> 32) - kmin) >> sh) >= bsel) {
+        if (ev[j] && (uint32_t)(e[j] >> 32) >= cutoff) {
             const uint32_t pos = atomicAdd(&ctl[3], 1u);
             if (pos < SCAP) sbuf[pos] = e[j];
         }

@@ -81,7 +81,7 @@ extern "C" int hdb_mfma_ksplit_slices(int dtype, int d);
 extern "C" int hdb_launch_mfma_ksplit(const ScanArgs* args, int dtype, int mode, int nq_launch, const void* q, const float* sqnorm,
                                       const float* qsq, const float* qscl, int blocks, void* stream);
 
-extern "C" int hdb_mfma_tile_rows(int dtype, int d) {
+static int mfma_exact_tile_rows(int dtype, int d) {
     const int elem = dtype == HDB_F16 ? 2 : dtype == HDB_F32 ? 4 : 0;
     if (!elem || d <= 0) return 0;
     if (hdb_mfma_ksplit_slices(dtype, d) > 0) return 16;                  // wide rows: K slices of 16-row stages (hdb_mfma_ksplit.hip)
@@ -93,9 +93,29 @@ extern "C" int hdb_mfma_tile_rows(int dtype, int d) {
     return 0;
 }
 
+// Rows of any width that is a multiple of 16 bytes and has no geometry of its own ride the next wider one as a single K slice
+// (hdb_mfma_anyd.h): -> that width, or 0.  fp16 d % 8 == 0 up to 1024, float32 d % 4 == 0 up to 768.
+extern "C" int hdb_mfma_anyd_pad(int dtype, int d) {
+    const int elem = dtype == HDB_F16 ? 2 : dtype == HDB_F32 ? 4 : 0;
+    if (!elem || d <= 0 || (d * elem) % 16 != 0 || mfma_exact_tile_rows(dtype, d) > 0) return 0;
+    static const int w16[] = {128, 256, 384, 512, 768, 1024}, w32[] = {128, 256, 384, 512, 768};
+    if (dtype == HDB_F16) { for (int w : w16) if (w >= d) return w; }
+    else { for (int w : w32) if (w >= d) return w; }
+    return 0;
+}
+
+#define HDB_ANYD_DECL(name) extern "C" int name(const ScanArgs* args, int dpad, int mode, int nq_launch, const void* q, const float* sqnorm, \
+                                              const float* qsq, const float* qscl, int blocks, void* stream)
+HDB_ANYD_DECL(hdb_launch_mfma_anyd_a); HDB_ANYD_DECL(hdb_launch_mfma_anyd_b); HDB_ANYD_DECL(hdb_launch_mfma_anyd_c); HDB_ANYD_DECL(hdb_launch_mfma_anyd_d);
+
+extern "C" int hdb_mfma_tile_rows(int dtype, int d) {
+    const int pad = hdb_mfma_anyd_pad(dtype, d);
+    return mfma_exact_tile_rows(dtype, pad ? pad : d);
+}
+
 // queries ONE launch of the MFMA scan covers (grid.y == 1): what a single-launch (mode 2) call can take
 extern "C" int hdb_mfma_batch_capacity(int dtype, int d) {
-    if (hdb_mfma_tile_rows(dtype, d) <= 0 || hdb_mfma_ksplit_slices(dtype, d) > 0) return 0;      // (K slices: the multi-kernel pipeline)
+    if (hdb_mfma_tile_rows(dtype, d) <= 0 || hdb_mfma_ksplit_slices(dtype, d) > 0 || hdb_mfma_anyd_pad(dtype, d) > 0) return 0;      // (K slices, odd widths: the multi-kernel pipeline)
     if (dtype == HDB_F32) return 128;
     return (d == 384 || d == 128 || d == 256 || d == 512 || d == 640) ? 256 : 128;      // two query tiles per wave (hdb_mfma_qt2.hip)
 }
@@ -144,6 +164,13 @@ extern "C" int hdb_launch_mfma_scan(const ScanArgs* args, int dtype, int mode, i
     if (blocks < 1) blocks = 1;
     if (mode == 2 && blocks > cus) blocks = cus;
     if (hdb_mfma_ksplit_slices(dtype, a.d) > 0) return mode == 2 ? (int)hipErrorNotSupported : hdb_launch_mfma_ksplit(args, dtype, mode, nq_launch, q16, sqnorm, qsq, qscl, blocks, stream);
+    if (const int pad = hdb_mfma_anyd_pad(dtype, a.d)) {               // a width without a geometry of its own: one slice of the next wider one
+        if (mode == 2) return (int)hipErrorNotSupported;
+        if (dtype == HDB_F16) return pad <= 384 ? hdb_launch_mfma_anyd_a(args, pad, mode, nq_launch, q16, sqnorm, qsq, qscl, blocks, stream)
+                                                : hdb_launch_mfma_anyd_b(args, pad, mode, nq_launch, q16, sqnorm, qsq, qscl, blocks, stream);
+        return pad <= 384 ? hdb_launch_mfma_anyd_c(args, pad, mode, nq_launch, q16, sqnorm, qsq, nullptr, blocks, stream)
+                          : hdb_launch_mfma_anyd_d(args, pad, mode, nq_launch, q16, sqnorm, qsq, nullptr, blocks, stream);
+    }
     if (dtype == HDB_F32) return hdb_launch_mfma_scan_f32(args, mode, nq_launch, q16, sqnorm, qsq, blocks, stream, f);
     if (dtype != HDB_F16) return (int)hipErrorNotSupported;
     // (mode 2 promises hdb_mfma_batch_capacity() queries in ONE launch: only the two-tile launcher holds more than 128, whatever the variant)

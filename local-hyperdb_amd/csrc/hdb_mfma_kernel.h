@@ -254,7 +254,8 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
         const uint4* src = reinterpret_cast<const uint4*>(KSL ? q16 + (int64_t)qq * a.ks_dfull + a.ks_off / ES : q16 + (int64_t)qq * D) + h;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            uint4 v = src[CPS * s];
+            const bool past = KSL && a.ks_valid > 0 && (CPS * s + h) * 16 >= a.ks_valid;      // rows narrower than the geometry: nothing there
+            uint4 v = past ? make_uint4(0, 0, 0, 0) : src[CPS * s];
             if (!q_ok[qt]) v = make_uint4(0, 0, 0, 0);
             Bq[qt][s] = *reinterpret_cast<Vec*>(&v);
         }
@@ -410,7 +411,9 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
             const int slot = pc * 64 + lane;
             const int r = slot / CPR, cpos = slot - r * CPR;
             const int rr = r <= (int)last ? r : (int)last;
-            const unsigned int off = (unsigned int)(rr * (int)pitch + (cpos ^ (r & 15)) * 16);
+            int ch = cpos ^ (r & 15);                                                  // which 16 bytes of the row sit at this place of its LDS image
+            if (KSL && a.ks_valid > 0 && ch * 16 >= a.ks_valid) ch = 0;                // past the end of a narrower row: its first chunk again (finite, times a zero query fragment)
+            const unsigned int off = (unsigned int)(rr * (int)pitch + ch * 16);
             __builtin_amdgcn_global_load_lds(HDB_GLOBAL_PTR(tile_base + off), HDB_LDS_PTR(sdst + pc * 1024), 16, 0, 2);
         }
     };
@@ -1002,7 +1005,9 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
             HDB_BSTAMP(7);
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
             bool all_in = true;
-            while (__hip_atomic_load(f.ctl + HDB_BATCH_CTL_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)G) {
+            // (only the owners of a query wait for everybody -- workgroup b owns queries b, b + G, ...: with fewer queries than
+            // workgroups the rest leave at once instead of polling the line the arrivals go to, see hdb_bits_fused.hip)
+            while ((int64_t)bidx < (int64_t)nq_all && __hip_atomic_load(f.ctl + HDB_BATCH_CTL_DONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned int)G) {
                 if (expired(t0)) { all_in = false; break; }
                 __builtin_amdgcn_s_sleep(8);
             }
@@ -1052,8 +1057,12 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
                     __syncthreads();
                 }
             };
-            hdb_finalize_body(fbuf, a.cand + (int64_t)q * a.cap, tot, q, a.cap, f.k, f.kk, f.row_base, f.idx_out, f.score_out, f.status,
-                              (ssq != ssq) ? 1 : 0, 0, nullptr, 1.f, rescore);
+            if constexpr (METRIC == 2)
+                hdb_finalize_body(fbuf, a.cand + (int64_t)q * a.cap, tot, q, a.cap, f.k, f.kk, f.row_base, f.idx_out, f.score_out, f.status,
+                                  (ssq != ssq) ? 1 : 0, 0, nullptr, 1.f, rescore);
+            else
+                hdb_finalize_fast(fbuf, a.cand + (int64_t)q * a.cap, tot, q, a.cap, f.k, f.kk, f.row_base, f.idx_out, f.score_out, f.status,
+                                  (ssq != ssq) ? 1 : 0, 0);
             __syncthreads();
         }
         // ---- leave: the last workgroup out zeroes the control block for the next launch

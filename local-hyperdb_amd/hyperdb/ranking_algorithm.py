@@ -21,6 +21,8 @@ call raises ``HyperDBNativeError`` instead of silently computing on the host.
 """
 from __future__ import annotations
 
+import math
+
 import numpy as np
 import torch
 
@@ -156,9 +158,13 @@ def euclidean_metric(vectors, query_vector, get_similarity_score=True):
 def check_and_binarize_vectors(vectors):
     """x > 0 -> 1 else 0, IN PLACE unless already binary (reference :116-126).  Host helper used
     to reproduce the reference's visible side effect on the caller's query array."""
-    unique_values = np.unique(vectors)
-    if any(np.array_equal(unique_values, ok) for ok in ([0, 1], [0], [1])):
+    # (the reference asks np.unique for exactly the value sets [0, 1], [0], [1]: "every element is 0 or 1", without the sort)
+    if isinstance(vectors, np.ndarray) and vectors.size and bool(((vectors == 0) | (vectors == 1)).all()):
         return vectors
+    if not isinstance(vectors, np.ndarray):
+        unique_values = np.unique(vectors)
+        if any(np.array_equal(unique_values, ok) for ok in ([0, 1], [0], [1])):
+            return vectors
     vectors[vectors > 0] = 1
     vectors[vectors <= 0] = 0
     return vectors
@@ -228,7 +234,8 @@ def hyperDB_ranking_algorithm_sort(vectors, query_vector, top_k=5, metric='cosin
         # same ValueError); a host query is checked here and staged once in a pinned buffer by the index
         on_device = isinstance(query_vector, torch.Tensor) and query_vector.is_cuda and ix.n > 1
         qh = query_vector.detach() if on_device else _query_host(query_vector)
-        if ix.has_nan or (not on_device and np.isnan(qh).any()):
+        # (one host query: a NaN anywhere makes q.q a NaN -- a dot product instead of an isnan pass and a reduction)
+        if ix.has_nan or (not on_device and (math.isnan(float(np.dot(qh, qh))) if (qh.ndim == 1 and qh.dtype.char in "fd") else np.isnan(qh).any())):
             raise ValueError(NAN_MESSAGE)
         _validate_metric(metric)
         if ix.n == 0:
@@ -245,14 +252,18 @@ def hyperDB_ranking_algorithm_sort(vectors, query_vector, top_k=5, metric='cosin
             k = max(0, min(int(top_k), ix.n))
             if k == 0:
                 return [], []
-            idx, sc = ix.topk(qh.reshape(1, -1), k, METRIC_IDS[metric])
+            # views of the index's pinned result record: converted once into the arrays handed back (int64 / float64 like the reference)
+            idx_v, sc_v, st_v = ix.topk_views(qh.reshape(1, -1), k, METRIC_IDS[metric])
+            if st_v[0] & _native.Q_NAN:
+                raise ValueError(NAN_MESSAGE)
+            idx, sc = idx_v[0].copy(), sc_v[0].astype(np.float64)
         finally:
             if had_bias:
                 ix.set_bias(None)
         if metric in ("hamming_distance", "jaccard_similarity") and isinstance(query_vector, np.ndarray) \
                 and query_vector.flags.writeable:
             check_and_binarize_vectors(query_vector)
-        return idx[0].astype(np.int64), sc[0].astype(np.float64)
+        return idx, sc
     finally:
         if owned:
             ix.close()

@@ -44,6 +44,42 @@ def stats(src, dst):
     print("wrote", dst, len(rows), "kernels")
 
 
+def legs(src, dst, ratio=1.35):
+    """Per-launch-size statistics out of the kernel TRACE (one row per dispatch): the default bench command runs the same kernel
+    on several matrices (headline 10M rows, the 1.25M-row shard leg, the small leg), which the plain --stats table averages together.
+    The dispatches of each hdb_* kernel are sorted by duration and cut into clusters wherever two neighbours differ by more than
+    `ratio`; every cluster is one line: name, calls, average / min / max ns.  bench.py's kernel_us of a leg is the average of the
+    cluster with that leg's launch count (200 headline calls + warm-up and api legs on the same matrix share a cluster)."""
+    import subprocess
+    rows = []
+    for path in glob.glob(os.path.join(src, "**", "*_kernel_trace.csv"), recursive=True):
+        rows += list(csv.DictReader(open(path)))
+    by = {}
+    for r in rows:
+        name = r["Kernel_Name"]
+        if "hdb_" not in name:
+            continue
+        by.setdefault(name, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    names = sorted(by)
+    dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
+    with open(dst, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Cluster", "Calls", "AverageNs", "MinNs", "MaxNs"])
+        for name, dn in zip(names, dem):
+            d = sorted(by[name])
+            cl, cur = [], [d[0]]
+            for x in d[1:]:
+                if x > cur[-1] * ratio:
+                    cl.append(cur); cur = [x]
+                else:
+                    cur.append(x)
+            cl.append(cur)
+            short = (dn or name).split("(")[0][:110]
+            for i, c in enumerate(cl):
+                w.writerow([short, i, len(c), round(sum(c) / len(c), 1), c[0], c[-1]])
+    print("wrote", dst)
+
+
 def pmc(fetch_dir, write_dir, needle, dst):
     def avg(d, counter):
         vals = [float(r["Counter_Value"])
@@ -109,6 +145,8 @@ def mfma(needle, flop, dst, dirs):
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "legs":
+        legs(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "mfma":
         mfma(sys.argv[2], float(sys.argv[3]), sys.argv[4], sys.argv[5:])
     else:

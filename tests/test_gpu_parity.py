@@ -654,7 +654,13 @@ def test_mfma_with_recency_bias(orc):
                                               # every multiple of 128 up to 1536 rides the matrix cores (16-row stages, 7-11 pieces per staging wave)
                                               (896, 40, "cosine_similarity", False), (1152, 33, "dot_product", True),
                                               (1280, 64, "euclidean_metric", False), (1408, 17, "cosine_similarity", True),
-                                              (896, 128, "euclidean_metric", True)])
+                                              (896, 128, "euclidean_metric", True),
+                                              # round 4: ANY width that is a multiple of 8 rides the next wider geometry as one K slice (hdb_mfma_anyd.h) --
+                                              # chunks past the end of a row are not fetched, the query fragments are zero there
+                                              (96, 16, "dot_product", False), (96, 64, "euclidean_metric", True), (200, 64, "cosine_similarity", True),
+                                              (200, 16, "euclidean_metric", False), (296, 16, "cosine_similarity", False), (304, 64, "dot_product", True),
+                                              (312, 130, "euclidean_metric", False), (1000, 16, "dot_product", False),
+                                              (1000, 64, "euclidean_metric", True), (8, 16, "cosine_similarity", False), (520, 40, "dot_product", False)])
 def test_mfma_shapes_and_euclidean(orc, d, nq, metric, bias):
     """Config-5 shaped case (d=768, Q=64, euclidean + time decay) and the other MFMA geometries."""
     import torch
@@ -883,7 +889,10 @@ def test_row_mask_mfma_equals_valu(orc, keep):
 @pytest.mark.parametrize("d,nq,metric,bias", [(384, 64, "cosine_similarity", False), (384, 130, "dot_product", True),
                                               (128, 5, "euclidean_metric", False), (256, 33, "cosine_similarity", True),
                                               (512, 17, "euclidean_metric", True), (768, 128, "dot_product", False),
-                                              (384, 9, "pearson_correlation", False)])
+                                              (384, 9, "pearson_correlation", False),
+                                              # round 4: any width that is a multiple of 4 floats (GloVe 100 / 200 / 300, ...)
+                                              (100, 16, "cosine_similarity", False), (300, 64, "dot_product", True), (200, 33, "euclidean_metric", False),
+                                              (300, 7, "pearson_correlation", False), (500, 16, "cosine_similarity", True), (700, 20, "euclidean_metric", True)])
 def test_fp32_mfma_batches_match_valu_and_oracle(orc, d, nq, metric, bias):
     """float32 matrices (the reference's default fp_precision): batches of 5+ queries ride the fp32 MFMA scan
     (v_mfma_f32_16x16x4_f32, exact fp32 products) and must agree with the VALU scan and the oracle to 1e-5."""
@@ -1983,7 +1992,9 @@ def test_local_flavour_equals_the_other_pipelines_and_exact(orc, dt, n, d):
     Q = rng.standard_normal((4, d)).astype(dt).astype(np.float32)
     Q[1] = V[n // 3].astype(np.float32)
     Q[2] = rng.standard_normal(d).astype(np.float32) * 37.5
-    ix = GpuIndex(V); ix.set_option("local_max_q", 4)      # (by rule calls of up to two queries take the local flavour: forced here)
+    ix = GpuIndex(V); ix.set_option("local_max_q", 4); ix.set_option("local_max_tiles", 16); ix.set_option("local_small", 1)
+    # (by rule the local flavour takes calls of up to two queries on more than 8192 rows and up to 4 tiles per workgroup: every
+    # shape it CAN take is forced here)
     maxq = (2 if d <= 384 else 1) if dt == np.float32 else (4 if d <= 768 else 2)
     rows = next(r for r in (64, 32, 16) if r * d * np.dtype(dt).itemsize <= 48 * 1024)
     tiles = (n + rows - 1) // rows
@@ -2051,7 +2062,7 @@ def test_local_flavour_cluster_in_one_tile_is_reported_and_rerun(dt):
     V = torch.randn((n, d), generator=g, device="cuda").to(torch.float16 if dt == np.float16 else torch.float32)
     noise = torch.randn((60, d), generator=g, device="cuda")
     mid = METRIC_IDS["cosine_similarity"]
-    ix = GpuIndex(V)
+    ix = GpuIndex(V); ix.set_option("local_max_tiles", 16)
     try:
         for trial, c0 in enumerate((64 * 100, 64 * 777 + 1, n - 64)):
             saved = V[c0:c0 + 60].clone()
@@ -2107,16 +2118,22 @@ def test_bits_local_flavour_equals_the_exchange_and_reports_clusters(n, d):
                     if int(ost[q].item()) == 0:
                         assert torch.equal(li[q], oi[q]) and torch.equal(ls[q], os_[q]), (metric, nq, k, q)
         ix.set_option("bits_local", 1)
-        c0 = 4096 * 3 + 100                                   # inside one 4096-row chunk
-        V[c0:c0 + 60] = V[c0:c0 + 1]
+        # 60 near-copies of one row, copy j with j signs flipped (scores d, d-1, ..., d-59), 64 rows apart inside ONE 4096-row chunk =
+        # one workgroup: it emits its eight best only, the other fifty (all far above the k-th best of the union) stay behind
+        c0 = 4096 * 3
+        base = V[c0].clone()
+        for j in range(60):
+            row = base.clone()
+            row[:j] = -row[:j]
+            V[c0 + 64 * j] = row
         ix.update(V)
-        q = V[c0].float().reshape(1, -1)
+        q = base.float().reshape(1, -1)
         mid = METRIC_IDS["hamming_distance"]
         li, ls, st = ix.topk_device(q, 100, mid)
-        assert int(st[0].item()) & 1, "60 rows at the maximum inside one chunk must fail the owner's check"
+        assert int(st[0].item()) & 1, "sixty graded near-copies inside one chunk must fail the owner's check"
         ei, es, _ = ix.topk_device(q, 100, mid, exact=True)
         hi, hs = ix.topk(q, 100, mid)
         assert np.array_equal(hi, ei.cpu().numpy()) and np.array_equal(hs, es.cpu().numpy())
-        assert float(hs[0][59]) == d and float(hs[0][60]) < d
+        assert float(hs[0][0]) == d and float(hs[0][20]) == d - 20
     finally:
         ix.close()

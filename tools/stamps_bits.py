@@ -34,22 +34,25 @@ def run():
         ix.set_option('bits_fused', 2)
         Q = bench.make_queries(nq, 384, torch.float16, dev).to(torch.float32)
         mid = METRIC_IDS['hamming_distance']
-        rows = []
-        for i in range(30):
-            t0 = time.perf_counter(); ix.topk_views(Q, 100, mid); wall = (time.perf_counter() - t0) * 1e6
-            assert ix.stat('fused') == 3
-            if i < 10: continue
-            buf = (ctypes.c_uint64 * (16 * 256))()
-            lib.hdb_debug_read_bits_stamps(buf, 256)
-            a = np.frombuffer(buf, dtype=np.uint64).reshape(256, 16).astype(np.int64)
-            rel = (a - a[:, 0].min()) / 100.0
-            if i == 29:
-                print('   filter done percentiles 0/10/50/90/100:', [round(float(np.percentile(rel[:, 5], p)), 1) for p in (0, 10, 50, 90, 100)],
-                      ' by blockIdx % 8:', [round(float(np.median(rel[x::8, 5])), 1) for x in range(8)], flush=True)
-            rows.append([wall, rel[:, 0].max()] + [np.median(rel[:, j]) for j in range(1, 11)] + [rel[:, j].max() for j in range(1, 11)])
-        r = np.median(np.array(rows), axis=0)
-        print(f"n={n} nq={nq} hamming: host wall {r[0]:.1f} us; median over workgroups: " + ", ".join(f"{k} {v:.1f}" for k, v in zip(names, r[1:12])), flush=True)
-        print("      max over workgroups: " + ", ".join(f"{k} {v:.1f}" for k, v in zip(names[1:], r[12:])), flush=True)
+        for loc in (1, 0):
+            ix.set_option('bits_local', loc)
+            print(f"--- bits_local = {loc}")
+            rows = []
+            for i in range(30):
+                t0 = time.perf_counter(); ix.topk_views(Q, 100, mid); wall = (time.perf_counter() - t0) * 1e6
+                assert ix.stat('fused') == 3
+                if i < 10: continue
+                buf = (ctypes.c_uint64 * (16 * 256))()
+                lib.hdb_debug_read_bits_stamps(buf, 256)
+                a = np.frombuffer(buf, dtype=np.uint64).reshape(256, 16).astype(np.int64)
+                rel = (a - a[:, 0].min()) / 100.0
+                if i == 29:
+                    print('   filter done percentiles 0/10/50/90/100:', [round(float(np.percentile(rel[:, 5], p)), 1) for p in (0, 10, 50, 90, 100)],
+                          ' by blockIdx % 8:', [round(float(np.median(rel[x::8, 5])), 1) for x in range(8)], flush=True)
+                rows.append([wall, rel[:, 0].max()] + [np.median(rel[:, j]) for j in range(1, 11)] + [rel[:, j].max() for j in range(1, 11)])
+            r = np.median(np.array(rows), axis=0)
+            print(f"n={n} nq={nq} hamming: host wall {r[0]:.1f} us; median over workgroups: " + ", ".join(f"{k} {v:.1f}" for k, v in zip(names, r[1:12])), flush=True)
+            print("      max over workgroups: " + ", ".join(f"{k} {v:.1f}" for k, v in zip(names[1:], r[12:])), flush=True)
         ix.close(); del V; torch.cuda.empty_cache()
 
 if __name__ == '__main__':

@@ -7,7 +7,7 @@ import numpy as np, torch
 from hyperdb._native import GpuIndex, METRIC_IDS
 g = torch.Generator(device='cuda').manual_seed(9)
 quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
-rows = (1_000, 8_192, 20_000, 100_000, 250_000, 500_000, 1_250_000) if not quick else (20_000, 100_000, 1_250_000)
+rows = (1_000, 8_192, 20_000, 100_000, 250_000, 500_000, 1_250_000, 10_000_000) if not quick else (20_000, 100_000, 1_250_000, 10_000_000)
 shapes = ((torch.float16, 384), (torch.float32, 384), (torch.float16, 768), (torch.float32, 768)) if not quick else ((torch.float16, 384),)
 def p50(ix, Q, mid, reps=60):
     for _ in range(5): ix.topk_views(Q, 100, mid)
@@ -17,6 +17,7 @@ def p50(ix, Q, mid, reps=60):
     return np.median(ts) * 1e6
 for dt, d in shapes:
     for n in rows:
+        if n * d * (2 if dt == torch.float16 else 4) > 9e9: continue
         V = torch.randn((n, d), generator=g, device='cuda').to(dt)
         ix = GpuIndex(V)
         passus = n * d * V.element_size() / 7e6
@@ -25,9 +26,9 @@ for dt, d in shapes:
             for nq in (1, 2, 4):
                 Q = torch.randn((nq, d), generator=g, device='cuda').to(dt).float()
                 mid = METRIC_IDS[metric]
-                ix.set_option("use_local", 1); a = p50(ix, Q, mid); tag = f"k{ix.stat('fused')}{'L' if ix.stat('local') else ''}"
-                ix.set_option("use_local", 0); b = p50(ix, Q, mid); tag0 = f"k{ix.stat('fused')}"
-                ix.set_option("use_local", 1)
+                ix.set_option("use_local", 1); ix.set_option("bits_local", 1); a = p50(ix, Q, mid); tag = f"k{ix.stat('fused')}{'L' if ix.stat('local') else ''}"
+                ix.set_option("use_local", 0); ix.set_option("bits_local", 0); b = p50(ix, Q, mid); tag0 = f"k{ix.stat('fused')}"
+                ix.set_option("use_local", 1); ix.set_option("bits_local", 1)
                 out.append(f"nq={nq}: {a:.0f} ({tag}) | r3 {b:.0f} ({tag0})")
             print(f"{str(dt)[6:]:8s} d={d:4d} n={n:8d} {metric[:9]:9s} pass {passus:6.1f} us | " + "   ".join(out), flush=True)
         ix.close(); del V; torch.cuda.empty_cache()
