@@ -416,6 +416,19 @@ def main():
                 pmc = json.load(open(ppath)).get(f"n={hi - lo},d={args.d},{args.dtype},q={bq},dot_product", {})
             except Exception:
                 pmc = {}
+        # what the matrix pipes of this chip sustain on this loop shape (tools/mfma_ceiling.hip: the same MFMA / ds_read_b128 / LDS-DMA
+        # cadence with random operands and nothing else -- no epilogue, no filter, no sample, no sorts), measured once per round
+        sustained = {}
+        cpath = os.path.join(ROOT, "profiles", "r4_mfma_ceiling.jsonl")
+        if os.path.exists(cpath):
+            try:
+                for line in open(cpath):
+                    if line.startswith("{"):
+                        j = json.loads(line)
+                        sustained[j["variant"].split(":")[0]] = j["pflops"] * 1e3
+            except Exception:
+                sustained = {}
+        ach_tf = flops / per_batch_kernel_s / 1e12 if per_batch_kernel_s else 0.0
         batched = {
             "workload": f"N={args.n} d={args.d} {args.dtype} Q={bq} dot_product top-{args.k}",
             "qps": bq * args.batch_steps / bel, "ms_per_batch": 1e3 * bel / args.batch_steps,
@@ -423,6 +436,10 @@ def main():
             "roofline_mfma": {"bound": "mfma", "achieved": flops / per_batch_kernel_s / 1e12 if per_batch_kernel_s else 0.0,
                               "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": flops / per_batch_kernel_s / 1e12 / MFMA_F16_PEAK_TFLOPS if per_batch_kernel_s else 0.0,
+                              "sustained_tflops": {"registers_only": sustained.get("regs"), "with_lds_fragment_reads": sustained.get("lds"),
+                                                   "with_lds_reads_and_hbm_stream": sustained.get("dma"),
+                                                   "source": "profiles/r4_mfma_ceiling.jsonl (tools/mfma_ceiling.hip, random fp16 operands, 2 waves per SIMD, in-kernel clock 1.66 / 1.69 / 1.47 GHz)"},
+                              "frac_of_sustained": (ach_tf / sustained["dma"]) if sustained.get("dma") else None,
                               "mfma_busy_frac": pmc.get("mfma_busy_frac"), "clock_ghz": pmc.get("clock_ghz"),
                               "clock_ghz_in_kernel": pmc.get("clock_ghz_in_kernel"), "pmc_source": pmc.get("source")},
             "roofline_hbm": {"bound": "hbm", "achieved": alg_bytes / per_batch_kernel_s / 1e9 if per_batch_kernel_s else 0.0,

@@ -152,6 +152,7 @@ struct hdb_index {
     int64_t local_small = 0;          // ... 1: also for matrices of up to 8192 rows (measured slower than the three launches)
     int64_t local_max_q = 1;          // ... for calls of up to this many queries (two to four: the batched single launch is faster -- 36 vs 45 us at 20k rows, profiles/r4_latency_map.txt)
     int64_t use_l1_tile = 1;          // manhattan: dense passes through the LDS-staged tile kernel (hdb_l1_tile.hip)
+    int64_t l1_packed = 1;            // ... fp16 rows and fp16-valued queries: packed fp16 differences (0: always float32, for A/B runs)
     int64_t use_batch1 = 1;           // 5+ queries (euclidean: 1+) on the matrix cores, k <= 128: the whole call in ONE launch per <= 256 queries (needs use_fused)
     int64_t fused_timeout_us = 2000;  // bound of every in-kernel spin of those kernels
     int64_t finalize_threads = 1024;  // workgroup size of hdb_finalize_kernel (256 | 512 | 1024)
@@ -371,6 +372,7 @@ extern "C" int hdb_set_option(hdb_index* ix, const char* name, int64_t value) {
     else if (!strcmp(name, "local_small")) ix->local_small = value;
     else if (!strcmp(name, "local_m")) ix->local_m = std::max<int64_t>(0, std::min<int64_t>(value, 64));
     else if (!strcmp(name, "use_l1_tile")) ix->use_l1_tile = value;
+    else if (!strcmp(name, "l1_packed")) ix->l1_packed = value;
     else if (!strcmp(name, "host_poll")) ix->host_poll = value;
     else if (!strcmp(name, "dyn_tiles")) ix->dyn_tiles = value;
     else if (!strcmp(name, "dyn_min_mb")) ix->dyn_min_mb = std::max<int64_t>(0, value);
@@ -503,7 +505,9 @@ static int run_scan(hdb_index* ix, ScanArgs& a, int mode, int cq, const QueryBuf
     } else if (a.metric == HDB_MANHATTAN && ix->use_l1_tile && cq >= 2 && a.tile_stride == 1 && !a.mask && !a.raw && a.n > HDB_CAND_CAP &&
                hdb_l1_tile_supported(ix->dtype, ix->d)) {
         // dense manhattan passes: tiles staged once in LDS, queries in registers, 8-16 queries per pass (hdb_l1_tile.hip)
-        LAUNCH_TRY(hdb_launch_l1_tile(&a, ix->dtype, mode, cq, (int)ix->max_blocks, st));
+        // (the tile kernel has no use for ScanArgs::dyn_heavy: 77 there = "keep the float32 arithmetic", set_option l1_packed 0)
+        ScanArgs al = a; al.dyn_heavy = ix->l1_packed ? 0 : 77;
+        LAUNCH_TRY(hdb_launch_l1_tile(&al, ix->dtype, mode, cq, (int)ix->max_blocks, st));
     } else if (mfma) {
         LAUNCH_TRY(hdb_launch_mfma_scan(&a, ix->dtype, mode, cq, qb.q16, ix->sqnorm, qb.qsq, qb.qscl, (int)ix->max_blocks, (int)ix->mfma_variant, st, nullptr));
     } else {

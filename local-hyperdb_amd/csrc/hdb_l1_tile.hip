@@ -49,24 +49,36 @@ __global__ __launch_bounds__(512) void hdb_l1_tile_kernel(ScanArgs a, int nq_end
     const int nqw = nqb - grp * per < per ? (nqb - grp * per > 0 ? nqb - grp * per : 0) : per;      // queries this wave really has
     const bool wave_active = nqw > 0;
 
-    // ---- this wave's queries in registers: lane (g4, l16) holds chunks l16 + 16 j of every query (E elements, as V stores them)
+    // ---- this wave's queries live in registers: lane (g4, l16) holds chunks l16 + 16 j of every query (E elements, as V stores them).
+    // fp16 rows, round 4: when every element of this wave's queries IS an fp16 number (the normal case: queries embedded in the store's
+    // precision) the differences are taken in packed fp16 -- v_pk_add_f16 (one rounding: v - q is exact for rows near the query, by
+    // Sterbenz, and off by at most 2^-11 of itself elsewhere; an error of the SUM of ~2^-11 / sqrt(d), far inside the 1e-3 contract),
+    // sign bits masked off, v_dot2c_f32_f16 against (1, 1) for the float32 sum: 3 instructions per TWO elements and query instead of
+    // 2 per element plus the conversions, and half the registers per query.  A query that is not an fp16 number keeps the float32
+    // path (its rounding would be a large share of a small |v - q|, see the header).  The choice is wave-uniform, made once, and
+    // selects one of two copies of the tile loop (the query registers of the other flavour never exist).
     constexpr int EPC = 16 / ES;                    // elements per 16-byte chunk of V
-    float qv[NQH][NJ][EPC];
     float thr[NQH];
 #pragma unroll
-    for (int q = 0; q < NQH; ++q) {
+    for (int q = 0; q < NQH; ++q) thr[q] = (MODE == 1 && q < nqw) ? a.thr[q0w + q - a.q0] : INFINITY;
+    auto query_src = [&](int q) {
         const int qq = q < nqw ? q0w + q : nq_end - 1;
-        const float* src = static_cast<const float*>(a.Q) + (int64_t)(qq < 0 ? 0 : qq) * D;
-        thr[q] = (MODE == 1 && q < nqw) ? a.thr[q0w + q - a.q0] : INFINITY;
+        return static_cast<const float*>(a.Q) + (int64_t)(qq < 0 ? 0 : qq) * D;
+    };
+    bool pk = false;
+    if constexpr (ES == 2) {
+        bool exact = wave_active && a.dyn_heavy != 77;        // (ScanArgs::dyn_heavy = 77: keep the float32 arithmetic -- set_option l1_packed 0, A/B runs)
+        for (int q = 0; q < nqw; ++q) {
+            const float* src = query_src(q);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int e = 0; e < EPC; e += 4) {
-                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (wave_active) x = *reinterpret_cast<const float4*>(src + (l16 + 16 * j) * EPC + e);
-                qv[q][j][e] = x.x; qv[q][j][e + 1] = x.y; qv[q][j][e + 2] = x.z; qv[q][j][e + 3] = x.w;
-            }
+                for (int e = 0; e < EPC; e += 4) {
+                    const float4 x = *reinterpret_cast<const float4*>(src + (l16 + 16 * j) * EPC + e);
+                    exact = exact && (float)(_Float16)x.x == x.x && (float)(_Float16)x.y == x.y && (float)(_Float16)x.z == x.z && (float)(_Float16)x.w == x.w;
+                }
         }
+        pk = __builtin_amdgcn_readfirstlane((int)__all(exact)) != 0;
     }
 
     const char* const Vb = reinterpret_cast<const char*>(a.V);
@@ -100,6 +112,28 @@ __global__ __launch_bounds__(512) void hdb_l1_tile_kernel(ScanArgs a, int nq_end
     const unsigned int smem_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(smem);
     const int u_own = hdb_owned_row(l16);
     int st_cur = 0;
+    auto tile_loop = [&](auto flavour) {
+    constexpr bool PK = decltype(flavour)::value != 0;
+    float qv[PK ? 1 : NQH][PK ? 1 : NJ][EPC];
+    unsigned int qpk[PK ? NQH : 1][PK ? NJ : 1][4];
+#pragma unroll
+    for (int q = 0; q < NQH; ++q) {
+        const float* src = query_src(q);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+            for (int e = 0; e < EPC; e += 4) {
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (wave_active) x = *reinterpret_cast<const float4*>(src + (l16 + 16 * j) * EPC + e);
+                if constexpr (PK) {
+                    const half2v h0 = {(_Float16)x.x, (_Float16)x.y}, h1 = {(_Float16)x.z, (_Float16)x.w};
+                    qpk[q][j][e / 2] = __builtin_bit_cast(unsigned int, h0); qpk[q][j][e / 2 + 1] = __builtin_bit_cast(unsigned int, h1);
+                } else {
+                    qv[q][j][e] = x.x; qv[q][j][e + 1] = x.y; qv[q][j][e + 2] = x.z; qv[q][j][e + 3] = x.w;
+                }
+            }
+        }
+    }
     for (; tA < ntiles; tA = tB, tB += G) {
         if (stager) { if (tB < ntiles) hdb_wait_vmcnt<NLOAD>(); else hdb_wait_vmcnt<0>(); }
         hdb_lds_barrier();                                // tile tA is in LDS; everyone is done with the tile before it
@@ -122,6 +156,26 @@ __global__ __launch_bounds__(512) void hdb_l1_tile_kernel(ScanArgs a, int nq_end
                     asm volatile("ds_read_b128 %0, %1" : "=v"(raw[u]) : "v"(ad));
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]));
+                if constexpr (PK) {
+                    const half2v ones = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        // (one cast of the whole chunk into a struct of four dwords: element-wise reads of the asm-produced vector, raw[u][dw],
+                        //  all come out as dword 0 -- the same quirk the float32 flavour works around with its half8 cast)
+                        const uint4 r4 = __builtin_bit_cast(uint4, raw[u]);
+                        const unsigned int rd[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+                        for (int q = 0; q < NQH; ++q)
+                            if (q < nqw) {
+#pragma unroll
+                                for (int dw = 0; dw < 4; ++dw) {
+                                    const half2v df = __builtin_bit_cast(half2v, rd[dw]) - __builtin_bit_cast(half2v, qpk[q][j][dw]);
+                                    const unsigned int ab = __builtin_bit_cast(unsigned int, df) & 0x7FFF7FFFu;
+                                    acc[u][q] = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, ab), ones, acc[u][q], false);
+                                }
+                            }
+                    }
+                } else {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     float x[EPC];
@@ -140,6 +194,7 @@ __global__ __launch_bounds__(512) void hdb_l1_tile_kernel(ScanArgs a, int nq_end
 #pragma unroll
                             for (int e = 0; e < EPC; ++e) acc[u][q] += fabsf(x[e] - qv[q][j][e]);
                         }
+                }
                 }
             }
             // ---- epilogue: one row per owning lane ((l16 & 3) == 0) and query
@@ -172,6 +227,9 @@ __global__ __launch_bounds__(512) void hdb_l1_tile_kernel(ScanArgs a, int nq_end
         }
         st_cur = st_cur == 2 ? 0 : st_cur + 1;
     }
+    };
+    if constexpr (ES == 2) { if (pk) tile_loop(HdbIC<1>()); else tile_loop(HdbIC<0>()); }
+    else tile_loop(HdbIC<0>());
     if (MODE == 1) {
         __syncthreads();
         for (int slot = 0; slot < nqb; ++slot) {
