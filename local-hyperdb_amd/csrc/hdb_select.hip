@@ -267,7 +267,8 @@ __global__ __launch_bounds__(1024) void hdb_finalize_kernel(const unsigned long 
                                                             int32_t* status, const int* qnan) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long buf[];
     const int q = blockIdx.x;
-    hdb_finalize_body(buf, cand + (int64_t)q * cap, cnt[q * HDB_CNT_STRIDE], q, cap, k, kk, row_base, idx_out, score_out, status,
+    // (round 4: the register-resident flavour where the list fits 16 entries per thread and k <= 256, else the general body)
+    hdb_finalize_fast(buf, cand + (int64_t)q * cap, cnt[q * HDB_CNT_STRIDE], q, cap, k, kk, row_base, idx_out, score_out, status,
                       qnan ? qnan[q] : 0, 0);
 }
 
