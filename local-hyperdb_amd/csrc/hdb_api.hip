@@ -25,6 +25,8 @@ extern "C" {
 int hdb_launch_scan(const ScanArgs* args, int dtype, int mode, int nq_launch, int max_blocks, void* stream);
 int hdb_launch_rownorm(const void* V, int64_t n, int d, int dtype, float* inv_norm, float* sqnorm, int* nan_flag, void* stream);
 int hdb_launch_qprep(const void* Q, int nq, int d, bool f64, float* qinv, float* qsq, int* qnan, void* q16, float* qscl, void* stream);
+int hdb_launch_qprep2(const void* Q, int nq, int d, bool f64, float* qinv, float* qsq, int* qnan, void* q16, float* qscl,
+                      float* thr_init, uint32_t* cnt_init, uint32_t* qbits, int W, void* stream);
 int hdb_launch_signpack(const void* V, int64_t n, int d, int dtype, int64_t row0, uint32_t* bits, void* stream);
 int hdb_launch_qsign(const void* Q, int nq, int d, bool f64, int W, uint32_t* qbits, void* stream);
 int hdb_launch_hamming(const ScanArgs* args, int mode, int nq_launch, const uint32_t* bits, int64_t npad, int W,
@@ -699,10 +701,15 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
                            // 100k rows 50 vs 148 us for four single launches in a row, 64 queries 67 vs 642; 10M rows 464 vs 524)
                            nq <= (ix->bits_max_q >= 0 ? ix->bits_max_q : 4);
                            // (the single launch prepares its queries itself)
-    if (!fused && !batch1 && !bits1_pre) LAUNCH_TRY(hdb_launch_qprep(dev_Q, nq, ix->d, f64, qinv, qsq, qnan, q16_in_prep ? q16 : nullptr, qscl, st));
+    // matrices of up to 8192 rows, one chunk of queries: the prep kernel also sets thr = -inf / an empty list and packs the query sign
+    // bits -- four (five) launches become three; the reference's own sizes live here (151 .. 10 000 documents)
+    const bool fold_small = small && !fused && !batch1 && !bits1_pre && !full_sort && nq <= cq_max;
+    if (!fused && !batch1 && !bits1_pre)
+        LAUNCH_TRY(hdb_launch_qprep2(dev_Q, nq, ix->d, f64, qinv, qsq, qnan, q16_in_prep ? q16 : nullptr, qscl, fold_small ? thr : nullptr,
+                                     fold_small ? cnt : nullptr, (fold_small && is_ham) ? qbits : nullptr, W, st));
     if (is_ham) {
         rc = ensure_bits(ix, st); if (rc) return rc;
-        if (!bits1_pre) LAUNCH_TRY(hdb_launch_qsign(dev_Q, nq, ix->d, f64, W, qbits, st));
+        if (!bits1_pre && !fold_small) LAUNCH_TRY(hdb_launch_qsign(dev_Q, nq, ix->d, f64, W, qbits, st));
     }
     const void* Qeff = dev_Q;
     int metric_eff = metric;
@@ -896,7 +903,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
         a.ks_partial_out = kbuf; a.ks_ld = ld_n;         // (K slices only; sample and exact passes index it by their own tile sequence)
 
         if (small) {
-            LAUNCH_TRY(hdb_launch_fill_thr(thr, cnt, cq, -INFINITY, st));
+            if (!fold_small) LAUNCH_TRY(hdb_launch_fill_thr(thr, cnt, cq, -INFINITY, st));
             rc = run_scan(ix, a, 1, cq, qb, mfma, st); if (rc) return rc;
         } else if (!exact) {
             // 1) strided row sample -> sample scores

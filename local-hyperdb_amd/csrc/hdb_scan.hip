@@ -303,13 +303,27 @@ __global__ __launch_bounds__(256) void hdb_rownorm_kernel(const T* V, int64_t n,
 
 // Per-query prep: qinv = 1/||q|| (0 -> 1), qsq = ||q||^2, NaN flag, and (q16 != nullptr) the scaled fp16 copy of
 // the query that the MFMA scan multiplies with, see hdb_q16_scaled.  One wave per query.
+// Round 4, matrices of up to 8192 rows (every row is a candidate): the kernel also does what two more launches did -- thr_init /
+// cnt_init != nullptr: threshold -inf and an empty candidate list for the query (hdb_fill_thr_kernel); qbits != nullptr: its sign bits
+// (hdb_qsign_kernel).  On the reference's own sizes (151 .. 10 000 documents) a launch is 4-5 us of a 25-us call.
 template <typename Acc>
 __global__ __launch_bounds__(64) void hdb_qprep_kernel(const Acc* Q, int nq, int d, float* qinv, float* qsq, int* qnan, _Float16* q16,
-                                                       float* qscl) {
+                                                       float* qscl, float* thr_init, uint32_t* cnt_init, uint32_t* qbits, int W) {
     const int q = blockIdx.x;
     if (q >= nq) return;
     Acc s = Acc(0);
     float amax = 0.f;
+    if (qbits) {                                // (same words as hdb_qsign_kernel: bit e of the query = x_e > 0)
+        for (int e0 = 0; e0 < d; e0 += 64) {
+            const int e = e0 + (int)threadIdx.x;
+            const unsigned long long m = __ballot(e < d && Q[(int64_t)q * d + e] > Acc(0));
+            if (threadIdx.x == 0) {
+                qbits[(int64_t)q * W + (e0 >> 5)] = (uint32_t)m;
+                if (e0 + 32 < d) qbits[(int64_t)q * W + (e0 >> 5) + 1] = (uint32_t)(m >> 32);
+            }
+        }
+    }
+    if (thr_init && threadIdx.x == 0) { thr_init[q] = -INFINITY; cnt_init[q * HDB_CNT_STRIDE] = 0u; }
     for (int e = threadIdx.x; e < d; e += 64) {
         const Acc x = Q[(int64_t)q * d + e];
         s = fma(x, x, s);                       // explicit fma: the fused kernel's prologue must reproduce this sum bit for bit
@@ -547,12 +561,16 @@ extern "C" int hdb_launch_rownorm(const void* V, int64_t n, int d, int dtype, fl
     return (int)hipGetLastError();
 }
 
+extern "C" int hdb_launch_qprep2(const void* Q, int nq, int d, bool f64, float* qinv, float* qsq, int* qnan, void* q16, float* qscl,
+                                 float* thr_init, uint32_t* cnt_init, uint32_t* qbits, int W, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (f64) hipLaunchKernelGGL(hdb_qprep_kernel<double>, dim3(nq), dim3(64), 0, st, (const double*)Q, nq, d, qinv, qsq, qnan, (_Float16*)q16, qscl, thr_init, cnt_init, qbits, W);
+    else hipLaunchKernelGGL(hdb_qprep_kernel<float>, dim3(nq), dim3(64), 0, st, (const float*)Q, nq, d, qinv, qsq, qnan, (_Float16*)q16, qscl, thr_init, cnt_init, qbits, W);
+    return (int)hipGetLastError();
+}
 extern "C" int hdb_launch_qprep(const void* Q, int nq, int d, bool f64, float* qinv, float* qsq, int* qnan, void* q16, float* qscl,
                                 void* stream) {
-    hipStream_t st = (hipStream_t)stream;
-    if (f64) hipLaunchKernelGGL(hdb_qprep_kernel<double>, dim3(nq), dim3(64), 0, st, (const double*)Q, nq, d, qinv, qsq, qnan, (_Float16*)q16, qscl);
-    else hipLaunchKernelGGL(hdb_qprep_kernel<float>, dim3(nq), dim3(64), 0, st, (const float*)Q, nq, d, qinv, qsq, qnan, (_Float16*)q16, qscl);
-    return (int)hipGetLastError();
+    return hdb_launch_qprep2(Q, nq, d, f64, qinv, qsq, qnan, q16, qscl, nullptr, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int hdb_launch_signpack(const void* V, int64_t n, int d, int dtype, int64_t row0, uint32_t* bits, void* stream) {

@@ -165,6 +165,10 @@ def check_and_binarize_vectors(vectors):
         unique_values = np.unique(vectors)
         if any(np.array_equal(unique_values, ok) for ok in ([0, 1], [0], [1])):
             return vectors
+    if isinstance(vectors, np.ndarray) and vectors.dtype.kind == "f":
+        # the reference's two masked assignments (x > 0 -> 1, x <= 0 -> 0; a NaN is neither and stays) in one masked copy
+        np.copyto(vectors, vectors > 0, casting="unsafe", where=(vectors == vectors))
+        return vectors
     vectors[vectors > 0] = 1
     vectors[vectors <= 0] = 0
     return vectors
