@@ -38,7 +38,7 @@ int hdb_launch_sample_thr(const float* scores, int64_t n, int64_t ld, int nq, ui
 int hdb_launch_collect(const float* scores, int64_t n, int64_t ld, int nq, const uint32_t* hist, int npass, uint32_t k, uint32_t* cnt,
                        unsigned long long* cand, uint32_t cap, uint32_t* tie_info, void* stream);
 int hdb_launch_finalize(const unsigned long long* cand, const uint32_t* cnt, uint32_t cap, int nq, uint32_t k, uint32_t kk,
-                        int64_t row_base, int64_t* idx_out, float* score_out, int32_t* status, const int* qnan, int threads, void* stream);
+                        int64_t row_base, int64_t* idx_out, float* score_out, int32_t* status, const int* qnan, int threads, int inf_status, void* stream);
 int hdb_launch_status_nan(const int* qnan, int nq, int32_t* status, void* stream);
 int hdb_launch_merge(const void* idx_base, int64_t idx_stride, const void* score_base, int64_t score_stride,
                      const void* status_base, int64_t status_stride, int parts, int nq, uint32_t k, int64_t* idx_out,
@@ -55,6 +55,7 @@ int hdb_launch_mfma_scan(const ScanArgs* args, int dtype, int mode, int nq_launc
 int hdb_mfma_batch_capacity(int dtype, int d);
 int hdb_mfma_ksplit_slices(int dtype, int d);
 int hdb_mfma_anyd_pad(int dtype, int d);
+int hdb_mfma_f32_split_min_q(int d);
 int hdb_l1_tile_supported(int dtype, int d);
 int hdb_launch_l1_tile(const ScanArgs* args, int dtype, int mode, int nq_launch, int max_blocks, void* stream);
 int hdb_bits_fused_supported(int metric, int nq, int W, uint32_t kk);
@@ -141,6 +142,9 @@ struct hdb_index {
     // knobs of the dispatch: -1 = the measured rule (tools/sweep_dispatch.py, profiles/r3_dispatch_few_queries.txt), else a fixed limit
     int64_t fused_max_q = -1;         // hdb_mfma_fused_kernel takes calls of up to this many queries
     int64_t f32_min_q = -1;           // float32 matrices: the matrix-core scan from this many queries on
+    int64_t f32_split = 1;            // ... as bf16 parts (hdb_mfma_f32s.hip) where that flavour exists, the matrix is finite and the call has at least
+    int64_t f32_split_min_q = -1;     //     this many queries (-1: hdb_mfma_f32_split_min_q(d), the measured crossover)
+    int flags_host = -1;              // host copy of *nan_flag (1 = a NaN row, 2 = a row with an infinite sum of squares); -1 = not fetched since the last build
     int64_t bits_max_q = -1;          // hamming / jaccard: the single launch (four queries at a time) up to this many queries
     int64_t host_direct = 1;          // hdb_topk_host: kernels write a pinned host record themselves (no D2H copy)
     int64_t dyn_tiles = 1;            // MFMA filter pass: hand tiles out from a counter (0: static split)
@@ -160,7 +164,7 @@ struct hdb_index {
     int64_t finalize_threads = 1024;  // workgroup size of hdb_finalize_kernel (256 | 512 | 1024)
     int64_t mfma_variant = 16;        // MFMA shape of the d=384 256-query pass (16 | 32)
     // stats of the last hdb_topk call
-    int64_t st_sample_rows = 0, st_sample_m = 0, st_path = 0, st_chunks = 0, st_mfma = 0, st_host_direct = 0, st_fused = 0, st_local = 0;
+    int64_t st_sample_rows = 0, st_sample_m = 0, st_path = 0, st_chunks = 0, st_mfma = 0, st_host_direct = 0, st_fused = 0, st_local = 0, st_f32s = 0;
     // host-side timing of hdb_topk_host (always on: four clock reads per call), cumulative since "host_timing_reset":
     // entry -> launch, the launch call itself, launch -> record complete (poll / stream wait), calls
     int64_t ht_pre_ns = 0, ht_launch_ns = 0, ht_wait_ns = 0, ht_calls = 0;
@@ -207,6 +211,7 @@ static int build_caches(hdb_index* ix, hipStream_t st) {
     }
     HIP_TRY(hipMemsetAsync(ix->nan_flag, 0, sizeof(int), st));
     if (ix->n > 0) LAUNCH_TRY(hdb_launch_rownorm(ix->V, ix->n, ix->d, ix->dtype, ix->inv_norm, ix->sqnorm, ix->nan_flag, st));
+    ix->flags_host = -1;
     ix->bits_valid = false; ix->bits_done = 0;         // a new matrix: nothing of the lazy caches survives
     ix->pscale_valid = false; ix->pscale_done = 0;
     ix->build_stream = st;
@@ -282,6 +287,7 @@ extern "C" int hdb_index_extend(hdb_index* ix, int64_t new_n, void* stream) {
     const char* tail = (const char*)ix->V + (size_t)old_n * ix->d * elem;
     LAUNCH_TRY(hdb_launch_rownorm(tail, new_n - old_n, ix->d, ix->dtype, ix->inv_norm + old_n, ix->sqnorm + old_n, ix->nan_flag, st));
     ix->n = new_n;
+    ix->flags_host = -1;
     ix->bits_valid = false;                            // (bits_done / pscale_done stay: the next hamming / pearson call packs the appended rows only)
     ix->pscale_valid = false;
     ix->bias = nullptr; ix->mask = nullptr;            // per-row inputs of the old length no longer apply
@@ -309,6 +315,7 @@ extern "C" int hdb_index_gather(hdb_index* ix, const int64_t* dev_rows, int64_t 
     if (ix->inv_norm) { (void)hipFree(ix->inv_norm); (void)hipFree(ix->sqnorm); }
     ix->inv_norm = inv2; ix->sqnorm = sq2; ix->cache_rows = rows;
     ix->V = dev_V_out; ix->n = m;
+    ix->flags_host = -1;
     ix->bits_valid = false; ix->pscale_valid = false; ix->bits_done = 0; ix->pscale_done = 0;
     ix->bias = nullptr; ix->mask = nullptr;
     ix->build_stream = st;
@@ -339,7 +346,14 @@ extern "C" int hdb_index_has_nan(hdb_index* ix, int* out_flag) {
     int h = 0;
     HIP_TRY(hipMemcpyAsync(&h, ix->nan_flag, sizeof(int), hipMemcpyDeviceToHost, ix->build_stream));
     HIP_TRY(hipStreamSynchronize(ix->build_stream));
-    *out_flag = h;
+    ix->flags_host = h;
+    *out_flag = h & 1;
+    return HDB_OK;
+}
+// Are all rows of the matrix finite with a finite sum of squares?  One 4-byte copy after each build, cached.
+static int matrix_is_finite(hdb_index* ix, bool* out) {
+    if (ix->flags_host < 0) { int f = 0; int rc = hdb_index_has_nan(ix, &f); if (rc != HDB_OK) return rc; }
+    *out = ix->flags_host == 0;
     return HDB_OK;
 }
 
@@ -384,6 +398,8 @@ extern "C" int hdb_set_option(hdb_index* ix, const char* name, int64_t value) {
     else if (!strcmp(name, "bits_local")) ix->bits_local = value;
     else if (!strcmp(name, "fused_max_q")) ix->fused_max_q = value;
     else if (!strcmp(name, "f32_min_q")) ix->f32_min_q = value;
+    else if (!strcmp(name, "f32_split")) ix->f32_split = value;
+    else if (!strcmp(name, "f32_split_min_q")) ix->f32_split_min_q = value;
     else if (!strcmp(name, "bits_max_q")) ix->bits_max_q = value;
     else if (!strcmp(name, "profile")) { ix->profile = value; ix->ev_used = 0; }
     else if (!strcmp(name, "host_timing_reset")) { ix->ht_pre_ns = ix->ht_launch_ns = ix->ht_wait_ns = ix->ht_calls = ix->ht_attr_ns = 0; }
@@ -398,6 +414,7 @@ extern "C" int hdb_get_stat(hdb_index* ix, const char* name, int64_t* value) {
     else if (!strcmp(name, "path")) *value = ix->st_path;
     else if (!strcmp(name, "chunks")) *value = ix->st_chunks;
     else if (!strcmp(name, "mfma")) *value = ix->st_mfma;
+    else if (!strcmp(name, "f32_split")) *value = ix->st_f32s;
     else if (!strcmp(name, "host_direct")) *value = ix->st_host_direct;
     else if (!strcmp(name, "fused")) *value = ix->st_fused;
     else if (!strcmp(name, "local")) *value = ix->st_local;
@@ -643,6 +660,13 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
                              // but 1 491 vs 1 466 at 5 M -- the single launch up to 4 M rows
                              !(ix->dtype == HDB_F16 && ix->d == 1024 && n > 4000000);
     const int tile_rows = (mfma || fused_shape) ? hdb_mfma_tile_rows(ix->dtype, ix->d) : 16;
+    // float32 rows on the matrix cores multiply in three bf16 parts (hdb_mfma_f32s.hip: 2.7x the rate of the float32 MFMAs, same
+    // 1e-5 contract) -- on finite matrices: the parts of an infinite element would cancel to NaN where np.dot keeps the infinity
+    bool f32s = false;
+    const int f32s_auto = hdb_mfma_f32_split_min_q(ix->d);
+    const int f32s_min = f32s_auto > 0 ? (int)(ix->f32_split_min_q > 0 ? ix->f32_split_min_q : f32s_auto) : 0;       // queries of the CALL (every launch of a call multiplies the same way)
+    if (mfma && ix->dtype == HDB_F32 && ix->f32_split && f32s_min > 0 && nq >= f32s_min) { const int rc = matrix_is_finite(ix, &f32s); if (rc != HDB_OK) return rc; }
+    ix->st_f32s = f32s ? 1 : 0;
     // anything else the matrix-core scan takes (5-256 dot / cosine queries, 1-256 euclidean ones), k <= 128: one launch per
     // <= bcap queries does preparation, sample, thresholds, the pass and every query's final sort (hdb_mfma_kernel.h, MODE 2)
     const int bcap = mfma ? hdb_mfma_batch_capacity(ix->dtype, ix->d) : 0;
@@ -863,7 +887,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
             ix->st_chunks++;
             ScanArgs a; base_args(ix, a, dev_Q, is_pearson ? (int)HDB_COSINE : metric);      // pearson: the cosine launch on queries the kernel centres, ...
             if (is_pearson) a.inv_norm = ix->pscale;                                          // ... row scale 1/(sd_v d)
-            a.bias = bias_eff; a.mask = nullptr; a.q0 = 0; a.nq = cq;
+            a.bias = bias_eff; a.mask = nullptr; a.q0 = 0; a.nq = cq; a.f32_split = f32s ? 1 : 0;
             a.ntiles = (n + tile_rows - 1) / tile_rows;
             a.cand = cand;
             a.tile_ctr = ix->dyn_tiles ? reinterpret_cast<uint32_t*>(ix->bctl) + HDB_BATCH_CTL_TILE : nullptr;
@@ -897,7 +921,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
         QueryBufs qb{qinv, qsq, qbits, f16_queries ? q16 : Qeff, f16_queries ? qscl : nullptr};
         ScanArgs a; base_args(ix, a, Qeff, metric_eff);
         if (is_pearson) a.inv_norm = ix->pscale;
-        a.q0 = q0; a.bias = bias_eff; a.mask = mask_eff;
+        a.q0 = q0; a.bias = bias_eff; a.mask = mask_eff; a.f32_split = f32s ? 1 : 0;
         a.thr = thr; a.cnt = cnt; a.cand = cand;
         a.ntiles = (n + tile_rows - 1) / tile_rows;
         a.ks_partial_out = kbuf; a.ks_ld = ld_n;         // (K slices only; sample and exact passes index it by their own tile sequence)
@@ -946,7 +970,8 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
             LAUNCH_TRY(hdb_launch_rescore_euclid(cand, cnt, HDB_CAND_CAP, cq, ix->V, ix->dtype, ix->d, (const float*)dev_Q, qsq, q0, ix->bias, st));
         LAUNCH_TRY(hdb_launch_finalize(cand, cnt, HDB_CAND_CAP, cq, (uint32_t)k, kk, ix->row_base,
                                        dev_idx + (int64_t)q0 * k, dev_score + (int64_t)q0 * k,
-                                       dev_status ? dev_status + q0 : nullptr, qnan + q0, (int)ix->finalize_threads, st));
+                                       dev_status ? dev_status + q0 : nullptr, qnan + q0, (int)ix->finalize_threads,
+                                       a.f32_split ? HDB_Q_UNDERFLOW : 0, st));      // (parts of an infinite query element cancel to NaN: exact re-run)
     }
     return HDB_OK;
 }

@@ -43,6 +43,7 @@ struct ScanArgs {
     uint32_t* tile_ctr;     // MFMA filter pass: zeroed counter that hands out tiles dynamically (nullptr: static split)
     int64_t dyn_min_bytes;  // ... only for passes of at least this many bytes of V per workgroup
     int32_t dyn_heavy;      // ... also when all eight waves multiply (more than half of a launch's query capacity)
+    int32_t f32_split;      // float32 rows on the MFMA scan: 1 = multiply as bf16 parts (hdb_mfma_f32s.hip) where that flavour exists
     // K-split MFMA scan (rows too wide for one wave's query fragments, hdb_mfma_ksplit.hip): one launch per K slice; a launch reads
     // `ks_bytes`-wide pieces of the rows at byte offset ks_off (row pitch ks_pitch, query pitch ks_dfull elements), starts its
     // accumulators from ks_partial_in (nullptr: zero) and, in MODE 3, stores the raw sums to ks_partial_out ([query][ks_ld])

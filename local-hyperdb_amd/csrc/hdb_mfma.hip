@@ -116,7 +116,7 @@ extern "C" int hdb_mfma_tile_rows(int dtype, int d) {
 // queries ONE launch of the MFMA scan covers (grid.y == 1): what a single-launch (mode 2) call can take
 extern "C" int hdb_mfma_batch_capacity(int dtype, int d) {
     if (hdb_mfma_tile_rows(dtype, d) <= 0 || hdb_mfma_ksplit_slices(dtype, d) > 0 || hdb_mfma_anyd_pad(dtype, d) > 0) return 0;      // (K slices, odd widths: the multi-kernel pipeline)
-    if (dtype == HDB_F32) return 128;
+    if (dtype == HDB_F32) return (d == 512 || d == 768) ? 64 : 128;      // (d = 512 / 768: the bf16-part flavour pairs its waves over K, hdb_mfma_kernel.h KP)
     return (d == 384 || d == 128 || d == 256 || d == 512 || d == 640) ? 256 : 128;      // two query tiles per wave (hdb_mfma_qt2.hip)
 }
 // bytes of the control block of the single-launch batched call for a grid of `wgs` workgroups
@@ -142,6 +142,13 @@ extern "C" int hdb_launch_mfma_scan_f16_qt2(const ScanArgs* args, int mode, int 
                                             const float* qsq, const float* qscl, int blocks, void* stream, const BatchArgs* f);
 extern "C" int hdb_launch_mfma_scan_f32(const ScanArgs* args, int mode, int nq_launch, const void* q, const float* sqnorm,
                                         const float* qsq, int blocks, void* stream, const BatchArgs* f);
+extern "C" int hdb_launch_mfma_scan_f32s(const ScanArgs* args, int mode, int nq_launch, const void* q, const float* sqnorm,
+                                         const float* qsq, int blocks, void* stream, const BatchArgs* f);
+// float32 widths whose scan also exists in bf16 parts (hdb_mfma_f32s.hip) -> the number of queries of a launch from which that
+// flavour is the faster one (0: no such flavour; the API decides per call, ScanArgs::f32_split).  d <= 384: up to 32 queries the float32 MFMAs keep up with HBM (measured,
+// profiles/r4_f32_bf16_parts.txt); d = 512 / 768: one wave cannot hold the query fragments of a whole row, the float32 flavour
+// runs 16-row tiles on one SIMD per 16 queries (2x a pass at any batch size), the bf16-part flavour splits K over two waves.
+extern "C" int hdb_mfma_f32_split_min_q(int d) { return (d == 128 || d == 384) ? 33 : d == 256 ? 9 : (d == 512 || d == 768) ? 1 : 0; }
 extern "C" int hdb_launch_mfma_scan_f16_wide(const ScanArgs* args, int mode, int nq_launch, const void* q16, const float* sqnorm,
                                              const float* qsq, const float* qscl, int blocks, void* stream, const BatchArgs* f);
 
@@ -171,7 +178,8 @@ extern "C" int hdb_launch_mfma_scan(const ScanArgs* args, int dtype, int mode, i
         return pad <= 384 ? hdb_launch_mfma_anyd_c(args, pad, mode, nq_launch, q16, sqnorm, qsq, nullptr, blocks, stream)
                           : hdb_launch_mfma_anyd_d(args, pad, mode, nq_launch, q16, sqnorm, qsq, nullptr, blocks, stream);
     }
-    if (dtype == HDB_F32) return hdb_launch_mfma_scan_f32(args, mode, nq_launch, q16, sqnorm, qsq, blocks, stream, f);
+    if (dtype == HDB_F32) return (a.f32_split > 0 && hdb_mfma_f32_split_min_q(a.d) > 0) ? hdb_launch_mfma_scan_f32s(args, mode, nq_launch, q16, sqnorm, qsq, blocks, stream, f)
+                                                                                   : hdb_launch_mfma_scan_f32(args, mode, nq_launch, q16, sqnorm, qsq, blocks, stream, f);
     if (dtype != HDB_F16) return (int)hipErrorNotSupported;
     // (mode 2 promises hdb_mfma_batch_capacity() queries in ONE launch: only the two-tile launcher holds more than 128, whatever the variant)
     if (nq_launch > 128 && hdb_mfma_qt2_supported(a.d) && (g_mfma_variant != 32 || (mode == 2 && a.d != 384)))

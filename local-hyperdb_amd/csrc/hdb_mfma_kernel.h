@@ -134,16 +134,70 @@ typedef __attribute__((address_space(1))) unsigned int hdb_gu32;
 
 template <int V> struct HdbIC { static constexpr int value = V; };
 
+// Element tag of the float32 row scan that multiplies in THREE bf16 PARTS (below): the bytes in memory are plain float32
+struct hdb_f32s { float x; __device__ __forceinline__ operator float() const { return x; } };
+typedef __bf16 hdb_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct HdbRaw8 { f32x4 lo, hi; };                     // 8 floats of a row (two 16-byte chunks)
+struct HdbParts3 { u32x4 p0, p1, p2; };               // the same 8 values as three bf16x8 fragments, v = p0 + p1 + p2 EXACTLY
+// Truncation split: p0 = the upper 16 bits of v (sign, exponent, 7 mantissa bits), r = v - p0 (exact: at most 16 significant bits
+// left), p1 = the upper 16 bits of r, p2 = r - p1 (at most 8 significant bits: a bf16 as it stands).  bf16 has float32's exponent
+// range, so nothing under- or overflows on the way that float32 itself would not.  9 VALU instructions per pair of values.
+// (hipcc 7.2: __builtin_bit_cast applied to an ELEMENT of an ext_vector reads element 0 whatever the index -- the bits go through
+// by-value scalars here)
+__device__ __forceinline__ unsigned int hdb_fbits(float f) { return __builtin_bit_cast(unsigned int, f); }
+__device__ __forceinline__ float hdb_bitsf(unsigned int u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ HdbParts3 hdb_split3(const HdbRaw8& r) {
+    HdbParts3 o;
+    const float x[8] = {r.lo[0], r.lo[1], r.lo[2], r.lo[3], r.hi[0], r.hi[1], r.hi[2], r.hi[3]};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float v0 = x[2 * j], v1 = x[2 * j + 1];
+        const unsigned int u0 = hdb_fbits(v0), u1 = hdb_fbits(v1);
+        const f32x2 v = {v0, v1};
+        const f32x2 h = {hdb_bitsf(u0 & 0xFFFF0000u), hdb_bitsf(u1 & 0xFFFF0000u)};
+        const f32x2 r1 = v - h;
+        const float r10 = r1[0], r11 = r1[1];
+        const unsigned int w0 = hdb_fbits(r10), w1 = hdb_fbits(r11);
+        const f32x2 g = {hdb_bitsf(w0 & 0xFFFF0000u), hdb_bitsf(w1 & 0xFFFF0000u)};
+        const f32x2 r2 = r1 - g;
+        const float r20 = r2[0], r21 = r2[1];
+        o.p0[j] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);                    // {upper half of u1, upper half of u0}
+        o.p1[j] = __builtin_amdgcn_perm(w1, w0, 0x07060302u);
+        o.p2[j] = __builtin_amdgcn_perm(hdb_fbits(r21), hdb_fbits(r20), 0x07060302u);
+    }
+    return o;
+}
+
 // MF: rows / queries per MFMA tile; E: element type of V and of the query fragments.  CPS = 16-byte chunks per k-step
 // (one ds_read_b128 per lane and k-step: lane group h = lane / MF holds chunk CPS*s + h of its row).
+// Eight floats -> [bf16(v) x 8][bf16(v - bf16(v)) x 8], round to nearest even; element order = the order hdb_split3 packs in
+typedef __bf16 hdb_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void hdb_round2(const f32x4& lo, const f32x4& hi, u32x4& a0, u32x4& a1) {
+    const float x[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x2 v = {x[2 * j], x[2 * j + 1]};
+        const hdb_bf16x2 b0 = __builtin_convertvector(v, hdb_bf16x2);
+        const unsigned int P0 = __builtin_bit_cast(unsigned int, b0);
+        const f32x2 h = {hdb_bitsf(P0 << 16), hdb_bitsf(P0 & 0xFFFF0000u)};
+        const f32x2 r = v - h;
+        const hdb_bf16x2 b1 = __builtin_convertvector(r, hdb_bf16x2);
+        a0[j] = P0; a1[j] = __builtin_bit_cast(unsigned int, b1);
+    }
+}
 template <int MF, typename E> struct MfmaShape;
 template <> struct MfmaShape<32, _Float16> {
-    using Acc = f32x16; using Vec = half8;
+    using Acc = f32x16; using Vec = half8; using BVec = Vec;
+    static constexpr int RPF = 1;
+    static constexpr bool CONV = false;
     static constexpr int CPS = 2, NGRP = 4;          // groups of 4 consecutive rows per lane per tile
     __device__ static __forceinline__ Acc mma(Vec a, Vec b, Acc c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 template <> struct MfmaShape<16, _Float16> {
-    using Acc = f32x4; using Vec = half8;
+    using Acc = f32x4; using Vec = half8; using BVec = Vec;
+    static constexpr int RPF = 1;
+    static constexpr bool CONV = false;
     static constexpr int CPS = 4, NGRP = 1;
     __device__ static __forceinline__ Acc mma(Vec a, Vec b, Acc c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
@@ -151,13 +205,37 @@ template <> struct MfmaShape<16, _Float16> {
 // fragment a lane reads holds 4 consecutive floats of its chunk, used as the k slots of four chained MFMAs: the
 // assignment of actual k indices to (MFMA, slot) pairs is a permutation that A and B share, which is all a sum needs.
 template <> struct MfmaShape<16, float> {
-    using Acc = f32x4; using Vec = f32x4;
+    using Acc = f32x4; using Vec = f32x4; using BVec = Vec;
+    static constexpr int RPF = 1;
+    static constexpr bool CONV = false;
     static constexpr int CPS = 4, NGRP = 1;
     __device__ static __forceinline__ Acc mma(Vec a, Vec b, Acc c) {
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], c, 0, 0, 0);
         return __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], c, 0, 0, 0);
+    }
+};
+// float32 data on the bf16 pipe.  A row value travels as TWO bf16 parts, a0 = bf16(v) and a1 = bf16(v - a0) (round to nearest even,
+// v_cvt_pk_bf16_f32): |v - a0 - a1| <= 2^-18 |v|.  The workgroup converts every staged tile IN PLACE, once, whatever the number of
+// queries (hdb_mfma_kernel's convert_tile): the 8 floats of a 32-byte group become [a0 x 8][a1 x 8], so the lane that owns those 8
+// k slots still reads its two 16-byte chunks and finds one bf16x8 fragment in each.  A query value is split once per call into
+// THREE parts that add up to it exactly (hdb_split3).  v . q = a0 q0 + a0 q1 + a1 q0 + a0 q2 + a1 q1 (the dropped a1 q2 is below
+// 2^-26 |v||q|): five v_mfma_f32_16x16x32_bf16 = 80 cycles for 16 x 16 x 32 products against 8 x 32 cycles of v_mfma_f32_16x16x4_f32.
+// Error of a score: at most 2^-18 = 3.8e-6 of |v||q| if every rounding pointed the same way; on real rows 1-2e-7, what float32
+// accumulation itself leaves (tools/time_f32_split.py).
+template <> struct MfmaShape<16, hdb_f32s> {
+    using Acc = f32x4; using Vec = HdbRaw8; using BVec = HdbParts3;
+    static constexpr int CPS = 8, NGRP = 1, RPF = 2;
+    static constexpr bool CONV = true;
+    __device__ static __forceinline__ Acc mma(const Vec& a, const HdbParts3& b, Acc c) {
+#define HDB_BF(x) __builtin_bit_cast(hdb_bf16x8, x)
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HDB_BF(a.hi), HDB_BF(b.p1), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HDB_BF(a.lo), HDB_BF(b.p2), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HDB_BF(a.hi), HDB_BF(b.p0), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HDB_BF(a.lo), HDB_BF(b.p1), c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(HDB_BF(a.lo), HDB_BF(b.p0), c, 0, 0, 0);
+#undef HDB_BF
     }
 };
 
@@ -188,7 +266,12 @@ template <> struct MfmaShape<16, float> {
 // AND multiplies, the LDS fragment traffic per MFMA halves.
 // KSL: the launch covers ONE K slice of D elements of rows that are wider (ScanArgs::ks_*): strided row and query addressing,
 // accumulators start from the partial sums of the slices before; MODE 3 (KSL only) stores the raw sums for the next slice.
-template <typename E, int MF, int QT, int D, int R, int RS, int MODE, int METRIC, bool HAS_BIAS, int NW = 8, bool KSL = false>
+// KP = 2 ("K parts", float32 rows as bf16 parts only): waves w and w + 4 share a query group and take one half of the k-steps each,
+// so a wave holds the query fragments of HALF a row (d = 512 / 768: 96 / 144 registers instead of 192 / 288) and all four SIMDs
+// multiply even for 16 queries.  Wave w + 4 hands its 16 x 16 partial sums over through LDS (its own, otherwise unused, segment of
+// the candidate list: 64 lanes x 16 bytes) behind a second barrier per tile; wave w adds them and runs the epilogue.  64 queries
+// per launch row (grid.y) instead of 128.
+template <typename E, int MF, int QT, int D, int R, int RS, int MODE, int METRIC, bool HAS_BIAS, int NW = 8, bool KSL = false, int KP = 1>
 __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* __restrict__ q16,
                                                        const float* __restrict__ aux0g, const float* __restrict__ qsq, const float* __restrict__ qscl,
                                                        int nq_end, BatchArgs f) {
@@ -199,8 +282,13 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
     using Acc = typename Shape::Acc;
     constexpr int NGRP = Shape::NGRP;
     constexpr int CPR = ROWB / 16;              // 16-byte chunks per row
-    constexpr int CPS = Shape::CPS;             // chunks per k-step (2 or 4)
-    constexpr int KS = CPR / CPS;               // k-steps (one fragment read each)
+    constexpr int CPS = Shape::CPS;             // chunks per k-step (2, 4 or 8)
+    constexpr int RPF = Shape::RPF;             // 16-byte chunks a lane reads per k-step and row tile (2: float32 rows in bf16 parts)
+    using BVec = typename Shape::BVec;
+    constexpr bool CONV = Shape::CONV;          // float32 tiles are turned into bf16 parts in place before they are multiplied
+    static_assert(CPR % CPS == 0 && (RPF == 1 || MF == 16), "k-steps");
+    constexpr int KS = CPR / CPS / KP;          // k-steps of this wave (one fragment read each)
+    static_assert(KP == 1 || (KP == 2 && Shape::CONV && NW == 8 && RS == 1 && QT == 1 && R == MF && (CPR / CPS) % 2 == 0 && (KS * CPS * 16) % 256 == 0 && MODE != 3), "K parts");
     // RS > 1 ("row split"): RS consecutive waves share one query group and take every RS-th row tile of the stage each,
     // so that few queries still spread their MFMAs over all four SIMDs (fp32 MFMAs bind long before HBM does)
     constexpr int RT = R / MF / RS;             // MFMA row tiles per stage and wave
@@ -238,11 +326,13 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
 
     // ---- this wave's queries --------------------------------------------------------------------
     const int part = RS > 1 ? w % RS : 0;       // which row tiles of a stage this wave multiplies: part, part + RS, ...
-    const int qw0 = a.q0 + blockIdx.y * ((NW / RS) * QPW) + (w / RS) * QPW;
+    const int qw0 = a.q0 + blockIdx.y * ((NW / RS / KP) * QPW) + ((w % (NW / KP)) / RS) * QPW;
+    const bool kp_upper = KP == 2 && w >= NW / 2;       // this wave multiplies the second half of the k-steps and has no epilogue
+    const int ks0 = kp_upper ? KS : 0;                  // first k-step (of the row's CPR / CPS) of this wave
     const bool wave_active = qw0 < nq_end;
     bool q_ok[QT];
     int ql[QT];
-    Vec Bq[QT][KS];
+    BVec Bq[QT][KS];
     float thr_l[QT], qinv_l[QT], qsq_l[QT];
     if constexpr (!ONE) {
 #pragma unroll
@@ -251,13 +341,17 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
         q_ok[qt] = q < nq_end;
         ql[qt] = q - a.q0;
         const int qq = q_ok[qt] ? q : (nq_end - 1);
-        const uint4* src = reinterpret_cast<const uint4*>(KSL ? q16 + (int64_t)qq * a.ks_dfull + a.ks_off / ES : q16 + (int64_t)qq * D) + h;
+        const uint4* src = reinterpret_cast<const uint4*>(KSL ? q16 + (int64_t)qq * a.ks_dfull + a.ks_off / ES : q16 + (int64_t)qq * D) + RPF * h;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const bool past = KSL && a.ks_valid > 0 && (CPS * s + h) * 16 >= a.ks_valid;      // rows narrower than the geometry: nothing there
-            uint4 v = past ? make_uint4(0, 0, 0, 0) : src[CPS * s];
-            if (!q_ok[qt]) v = make_uint4(0, 0, 0, 0);
-            Bq[qt][s] = *reinterpret_cast<Vec*>(&v);
+            uint4 v[RPF];
+#pragma unroll
+            for (int u = 0; u < RPF; ++u) {
+                const bool past = KSL && a.ks_valid > 0 && (CPS * (s + ks0) + RPF * h + u) * 16 >= a.ks_valid;      // rows narrower than the geometry: nothing there
+                v[u] = (past || !q_ok[qt]) ? make_uint4(0, 0, 0, 0) : src[CPS * (s + ks0) + u];
+            }
+            if constexpr (RPF == 1) Bq[qt][s] = *reinterpret_cast<Vec*>(&v[0]);
+            else Bq[qt][s] = hdb_split3(HdbRaw8{*reinterpret_cast<f32x4*>(&v[0]), *reinterpret_cast<f32x4*>(&v[RPF - 1])});
         }
         thr_l[qt] = 0.f; qinv_l[qt] = 1.f; qsq_l[qt] = 0.f;
         if (q_ok[qt]) {
@@ -343,6 +437,16 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
                         v[4] = (_Float16)(x1.x * scale); v[5] = (_Float16)(x1.y * scale); v[6] = (_Float16)(x1.z * scale); v[7] = (_Float16)(x1.w * scale);
                         if (!q_ok[qt]) v = Vec{0, 0, 0, 0, 0, 0, 0, 0};
                         Bq[qt][s] = v;
+                    } else if constexpr (RPF == 2) {
+                        const float4* src = reinterpret_cast<const float4*>(Qf + (int64_t)qq * D + (CPS * (s + ks0) + 2 * h) * 4);
+                        float4 x0 = src[0], x1 = src[1];
+                        if (centre) {
+                            const float mq = mean_l[qt];
+                            x0.x -= mq; x0.y -= mq; x0.z -= mq; x0.w -= mq; x1.x -= mq; x1.y -= mq; x1.z -= mq; x1.w -= mq;
+                        }
+                        HdbRaw8 v = {f32x4{x0.x, x0.y, x0.z, x0.w}, f32x4{x1.x, x1.y, x1.z, x1.w}};
+                        if (!q_ok[qt]) v = HdbRaw8{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+                        Bq[qt][s] = hdb_split3(v);
                     } else {
                         float4 x0 = *reinterpret_cast<const float4*>(Qf + (int64_t)qq * D + (CPS * s + h) * 4);
                         if (centre) { const float mq = mean_l[qt]; x0.x -= mq; x0.y -= mq; x0.z -= mq; x0.w -= mq; }
@@ -353,7 +457,11 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
                 }
             } else {
 #pragma unroll
-                for (int s = 0; s < KS; ++s) { if constexpr (ES == 2) Bq[qt][s] = Vec{0, 0, 0, 0, 0, 0, 0, 0}; else Bq[qt][s] = Vec{0.f, 0.f, 0.f, 0.f}; }
+                for (int s = 0; s < KS; ++s) {
+                    if constexpr (ES == 2) Bq[qt][s] = Vec{0, 0, 0, 0, 0, 0, 0, 0};
+                    else if constexpr (RPF == 2) Bq[qt][s] = HdbParts3{u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}, u32x4{0u, 0u, 0u, 0u}};
+                    else Bq[qt][s] = Vec{0.f, 0.f, 0.f, 0.f};
+                }
             }
             thr_l[qt] = 0.f; qinv_l[qt] = 1.f; qsq_l[qt] = 0.f;
             if (q_ok[qt]) {
@@ -374,7 +482,7 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
     // Waves 0-3 ("A") and 4-7 ("B") are the two waves of each SIMD.  B runs its threshold epilogue one tile
     // late so that the two waves of a SIMD do not reach MFMA phase, epilogue and barrier in lock-step.
     const bool grpB = NW == 4 || w >= 4;          // the waves that stage (all four of a four-wave workgroup)
-    const bool defer = NW == 4 ? w >= 2 : w >= 4;  // ... and the ones whose threshold epilogue runs one tile late
+    const bool defer = KP == 2 ? false : NW == 4 ? w >= 2 : w >= 4;  // ... and the ones whose threshold epilogue runs one tile late
     HDB_BSTAMP(1);
     // B also stages every tile (see the note on staging roles at the top of this file); with up to 4*MF*QT queries in a
     // pass the B waves have no queries and do nothing else.
@@ -469,7 +577,7 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
     // multiplies for a quarter of a round; waves 4-7, which stage, never wait for the counter.  The request goes out LOOK
     // rounds (~3 us of streaming, the counter answers in ~1.5 us) before the chunk is needed; the answer is handed over
     // through LDS.
-    const bool heavy = NW == 4 || (nq_end - (a.q0 + (int)blockIdx.y * ((8 / RS) * QPW))) > (4 / RS) * QPW;    // all waves multiply
+    const bool heavy = NW == 4 || KP == 2 || (nq_end - (a.q0 + (int)blockIdx.y * ((8 / RS) * QPW))) > (4 / RS) * QPW;    // all waves multiply
     const int64_t G = gstep, bidx = blockIdx.x;
     // Measured (10 M rows, 8-64 queries, static -> dynamic): d=768 2.29 -> 2.18 ms, d=1536 (2.5 M rows) 1.149 -> 1.109,
     // d=512 (5 M) 0.775 -> 0.764, d=384 1.120 -> 1.106; but d=128 401 -> 438 us, d=256 (5 M) 394 -> 404, d=384 at 2.5 M rows
@@ -529,6 +637,38 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
         if ((HDB_MFMA_KNOCKOUT & 2) && gp > 3) return;           // knock-out: the ring keeps its first three tiles
         if (grpB) { issue_rows(row0, st); issue_aux(row0, st); }
     };
+    // CONV (float32 rows as bf16 parts, MfmaShape<16, hdb_f32s>): a staging wave turns the pieces IT staged into [a0 x 8][a1 x 8]
+    // groups, in place, as soon as its own vmcnt says they have landed -- one tile ahead of the multiplying waves, so the round's
+    // one barrier still separates writer and readers.  32-byte slot sl of a stage (row r = sl / (CPR/2)) holds the chunks 2g and
+    // 2g+1 of its row, the odd one first where the row's swizzle (r & 15) is odd.  Two 1-KiB pieces = 64 slots per step.
+    auto convert_own = [&](int st) __attribute__((always_inline)) {
+        if constexpr (CONV) {
+            static_assert(NW == 8 && PPL % 4 == 0, "conversion shares");
+            const unsigned int cbase = (unsigned int)(uintptr_t)HDB_LDS_PTR(smem) + (unsigned int)(st * STAGE);
+#pragma unroll
+            for (int j = 0; j < PPL; j += 4) {                  // four pieces = two slots per lane and step: four reads in flight
+                unsigned int alo[2];
+                f32x4 clo[2], chi[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const unsigned int pc = (unsigned int)((w & 3) + 4 * (j + 2 * u + (lane >> 5)));
+                    const unsigned int sl = pc * 32u + (unsigned int)(lane & 31);
+                    const unsigned int odd = (sl / (CPR / 2)) & 1u;
+                    alo[u] = cbase + sl * 32u + odd * 16u;
+                }
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(clo[0]), "=&v"(chi[0]), "=&v"(clo[1]), "=&v"(chi[1])
+                             : "v"(alo[0]), "v"(alo[0] ^ 16u), "v"(alo[1]), "v"(alo[1] ^ 16u) : "memory");
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    u32x4 a0, a1;
+                    hdb_round2(clo[u], chi[u], a0, a1);
+                    asm volatile("ds_write_b128 %0, %1" :: "v"(alo[u]), "v"(a0) : "memory");
+                    asm volatile("ds_write_b128 %0, %1" :: "v"(alo[u] ^ 16u), "v"(a1) : "memory");
+                }
+            }
+        }
+    };
     int64_t tA, tB, tC = 0, rA, rB, rC = 0; bool vA, vB, vC = false;       // tile / first row / existence of sequence positions i, i+1, i+2
     int st_cur = 0;                                  // ring slot of sequence position i
     bool had_tiles = false;
@@ -542,14 +682,20 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
         had_tiles = vA;
         if (vA) issue(rA, st_cur);
         if (vB) issue(rB, st_cur == 2 ? 0 : st_cur + 1);
+        if constexpr (CONV) {
+            if (grpB && vA) {                                // the first tile of the pass: converted before the first barrier
+                if (vB) hdb_wait_vmcnt<PPL + NAUX>(); else hdb_wait_vmcnt<0>();
+                convert_own(st_cur);
+            }
+        }
     };
     begin_pass();
 
     const unsigned int smem_addr = (unsigned int)(uintptr_t)HDB_LDS_PTR(smem);
     // per-lane LDS read address: row rl of a row tile; chunk (CPS*s + h) ^ rx of k-step s is at byte
     // ((16*CPS*s) ^ hx) of the row image, hx = (h ^ rx) << 4  (CPS*s and h occupy disjoint bits)
-    const unsigned int rd_base = (unsigned int)((rl + part * MF) * CPR * 16);
-    const unsigned int hx = (unsigned int)((h ^ (rl & 15)) << 4);
+    const unsigned int rd_base = (unsigned int)((rl + part * MF) * CPR * 16) + (unsigned int)(ks0 * CPS * 16);     // (a multiple of 256: above the swizzle bits)
+    const unsigned int hx = (unsigned int)(((RPF * h) ^ (rl & 15)) << 4);      // (RPF == 2: the lane's second chunk is at this address ^ 16)
     // first of the 4 consecutive tile rows this lane's accumulator group g holds
     auto grp_row = [&](int rt, int g) { const int rg = part + RS * rt; return MF == 32 ? rg * 32 + 8 * g + 4 * h : rg * 16 + 4 * h; };
 
@@ -671,25 +817,46 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
             // lgkmcnt(n*RT) = "all but the n*RT newest LDS ops are back" = the oldest pending step's fragments;
             // stray scalar loads can only make that wait longer, never shorter.
             const unsigned int sb_addr = smem_addr + (unsigned int)(st_cur * STAGE) + rd_base;
-            constexpr int PF = QT == 2 ? 2 : 3;                // k-steps of LDS prefetch (PF+1 fragment sets; two query tiles: registers)
+            constexpr int PF = (RPF == 2 && RT >= 2) ? 1 : (QT == 2 || RPF == 2) ? 2 : 3;  // k-steps of LDS prefetch (PF+1 fragment sets; two query tiles, two chunks per lane: registers)
             Vec abuf[PF + 1][RT];
             auto fetch = [&](int s, Vec (&dst)[RT]) {
                 const unsigned int ad = sb_addr + ((unsigned int)(16 * CPS * s) ^ hx);
+                if constexpr (RPF == 2) {
+                    const unsigned int ad1 = ad ^ 16u;
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(dst[0].lo) : "v"(ad));
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(dst[0].hi) : "v"(ad1));
+                    if constexpr (RT > 1) {
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[1].lo) : "v"(ad), "i"(RS * MF * CPR * 16));
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[1].hi) : "v"(ad1), "i"(RS * MF * CPR * 16));
+                    }
+                    if constexpr (RT > 2) {
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[2].lo) : "v"(ad), "i"(2 * RS * MF * CPR * 16));
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[2].hi) : "v"(ad1), "i"(2 * RS * MF * CPR * 16));
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[RT - 1].lo) : "v"(ad), "i"(3 * RS * MF * CPR * 16));
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[RT - 1].hi) : "v"(ad1), "i"(3 * RS * MF * CPR * 16));
+                    }
+                } else {
                 asm volatile("ds_read_b128 %0, %1" : "=v"(dst[0]) : "v"(ad));
                 if constexpr (RT > 1) { if ((HDB_MFMA_KNOCKOUT & 8) && RT == 4) dst[1] = dst[0]; else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[1]) : "v"(ad), "i"(RS * MF * CPR * 16)); }
                 if constexpr (RT > 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[2]) : "v"(ad), "i"(2 * RS * MF * CPR * 16));
                 if constexpr (RT > 3) { if (HDB_MFMA_KNOCKOUT & 8) dst[3] = dst[2]; else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[3]) : "v"(ad), "i"(3 * RS * MF * CPR * 16)); }
+                }
             };
             // wait until at most `pend` k-steps of fragment reads are outstanding: lgkmcnt(pend*RT)
             auto wait_frag = [&](int pend, Vec (&f)[RT]) {
                 static_assert(RT == 1 || RT == 2 || RT == 4, "RT");
 #define HDB_WAITF(N)                                                                                               \
                 do {                                                                                               \
+                    if constexpr (RPF == 2) {                                                                      \
+                        if constexpr (RT == 1) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(f[0].lo), "+v"(f[0].hi)); \
+                        else if constexpr (RT == 2) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(f[0].lo), "+v"(f[0].hi), "+v"(f[RT - 1].lo), "+v"(f[RT - 1].hi)); \
+                        else asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(f[0].lo), "+v"(f[0].hi), "+v"(f[1].lo), "+v"(f[1].hi), "+v"(f[RT - 2].lo), "+v"(f[RT - 2].hi), "+v"(f[RT - 1].lo), "+v"(f[RT - 1].hi)); \
+                    } else                                                                                         \
                     if constexpr (RT == 1) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(f[0]));                  \
                     else if constexpr (RT == 2) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(f[0]), "+v"(f[1])); \
                     else asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3])); \
                 } while (0)
-                const int cnt = pend * (((HDB_MFMA_KNOCKOUT & 8) && RT == 4) ? 2 : RT);
+                const int cnt = pend * RPF * (((HDB_MFMA_KNOCKOUT & 8) && RT == 4) ? 2 : RT);
                 if (cnt >= 12) HDB_WAITF(12); else if (cnt == 8) HDB_WAITF(8); else if (cnt == 6) HDB_WAITF(6);
                 else if (cnt == 4) HDB_WAITF(4); else if (cnt == 3) HDB_WAITF(3); else if (cnt == 2) HDB_WAITF(2);
                 else if (cnt == 1) HDB_WAITF(1); else HDB_WAITF(0);
@@ -704,7 +871,7 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
 #pragma unroll
                     for (int e = 0; e < 4 * NGRP; ++e) acc[qt][rt][e] = 0.f;
             if constexpr (KSL) {
-                if (a.ks_partial_in) {               // the sums of the K slices before this one (same layout as MODE 0's scores)
+                if (a.ks_partial_in && !kp_upper) {  // the sums of the K slices before this one (same layout as MODE 0's scores)
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
@@ -732,6 +899,20 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
                 for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
                     for (int qt = 0; qt < QT; ++qt) acc[qt][rt] = Shape::mma(abuf[s % (PF + 1)][rt], Bq[qt][s], acc[qt][rt]);
+            }
+            if constexpr (KP == 2) {                 // the second half of K: hand the partial sums over (this wave's own list segment)
+                // (s_nop: the hazard recognizer does not see an inline-asm LDS store as a reader of the matrix pipe's result registers;
+                //  up to 19 wait states between the last MFMA and a store of its accumulator, ISA guide 4.5)
+                if (kp_upper) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3\n\tds_write_b128 %0, %1" :: "v"(seg_cb + (unsigned int)lane * 16u), "v"(acc[0][0]) : "memory");
+            }
+        }
+        if constexpr (KP == 2) hdb_lds_barrier();
+        if (wave_active && !kp_upper) {
+            const int64_t row0 = rA;
+            if constexpr (KP == 2) {
+                f32x4 pv;
+                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(pv) : "v"(seg_cb + (unsigned int)(4 * HDB_MFMA_SEG * 8) + (unsigned int)lane * 16u) : "memory");
+                acc[0][0] += pv;
             }
 
             // ---- epilogue, first half: turn the dot products into the values that are stored (MODE 0) or
@@ -819,6 +1000,12 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
                 else row0_prev = row0;
             }
         }
+        if constexpr (CONV) {
+            if (grpB && vB) {                                // tile i+1 (issued a round ago): this wave's pieces are in -> bf16 parts
+                if (vC) hdb_wait_vmcnt<PPL + NAUX>(); else hdb_wait_vmcnt<0>();
+                convert_own(st_cur == 2 ? 0 : st_cur + 1);
+            }
+        }
         st_cur = st_cur == 2 ? 0 : st_cur + 1;
         tA = tB; rA = rB; vA = vB; tB = tC; rB = rC; vB = vC;
     }
@@ -851,7 +1038,7 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
         begin_pass();
         // ---- publish: granules [query][workgroup][2 h], [.. + 1] = {epoch, key of this lane's largest, second largest}: ONE 16-byte
         // store per lane and query tile, the four lanes of a query fill its 64-byte line
-        if (wave_active) {
+        if (wave_active && !kp_upper) {
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
                 if (q_ok[qt]) {
@@ -1059,10 +1246,10 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
             };
             if constexpr (METRIC == 2)
                 hdb_finalize_body(fbuf, a.cand + (int64_t)q * a.cap, tot, q, a.cap, f.k, f.kk, f.row_base, f.idx_out, f.score_out, f.status,
-                                  (ssq != ssq) ? 1 : 0, 0, nullptr, 1.f, rescore);
+                                  (ssq != ssq) ? 1 : 0, (RPF == 2 && ssq - ssq != 0.f) ? HDB_Q_UNDERFLOW : 0, nullptr, 1.f, rescore);
             else
                 hdb_finalize_fast(fbuf, a.cand + (int64_t)q * a.cap, tot, q, a.cap, f.k, f.kk, f.row_base, f.idx_out, f.score_out, f.status,
-                                  (ssq != ssq) ? 1 : 0, 0);
+                                  (ssq != ssq) ? 1 : 0, (RPF == 2 && ssq - ssq != 0.f) ? HDB_Q_UNDERFLOW : 0);      // parts of an infinite value cancel to NaN: exact re-run
             __syncthreads();
         }
         // ---- leave: the last workgroup out zeroes the control block for the next launch
@@ -1097,15 +1284,15 @@ static size_t mfma_batch_lds_bytes(int stage_bytes) {
     return (scan > fin ? scan : fin) + 2 * HDB_BATCH_MAXQ * 4 + 512;
 }
 
-template <typename E, int MF, int QT, int D, int R, int RS, int MODE, int METRIC, bool HAS_BIAS>
+template <typename E, int MF, int QT, int D, int R, int RS, int MODE, int METRIC, bool HAS_BIAS, int KP = 1>
 static int launch_one(const ScanArgs& a, const void* q16, const float* aux0, const float* qsq, const float* qscl, int nq_launch, int blocks, hipStream_t st,
                       const BatchArgs* f) {
-    auto kern = hdb_mfma_kernel<E, MF, QT, D, R, RS, MODE, METRIC, HAS_BIAS>;
+    auto kern = hdb_mfma_kernel<E, MF, QT, D, R, RS, MODE, METRIC, HAS_BIAS, 8, false, KP>;
     const size_t lds = MODE == 2 ? mfma_batch_lds_bytes(R * D * (int)sizeof(E)) : mfma_lds_bytes(R * D * (int)sizeof(E));
     static unsigned long long attr_done = 0;          // per instantiation, one bit per device
     hipError_t e = hdb_lds_attr_once(reinterpret_cast<const void*>(kern), (int)lds, &attr_done);
     if (e != hipSuccess) return (int)e;
-    const dim3 grid(blocks, (nq_launch + (8 / RS) * MF * QT - 1) / ((8 / RS) * MF * QT));
+    const dim3 grid(blocks, (nq_launch + (8 / RS / KP) * MF * QT - 1) / ((8 / RS / KP) * MF * QT));
     if (MODE == 2 && (grid.y != 1 || !f || a.q0 != 0)) return (int)hipErrorInvalidValue;
     BatchArgs fa = BatchArgs();
     if (f) fa = *f;
@@ -1154,25 +1341,25 @@ static int launch_four_waves(const ScanArgs& a, const void* q16, const float* qs
     return (int)hipGetLastError();
 }
 
-template <typename E, int MF, int QT, int D, int R, int RS, int MODE>
+template <typename E, int MF, int QT, int D, int R, int RS, int MODE, int KP = 1>
 static int launch_metric(const ScanArgs& a, const void* q16, const float* sqnorm, const float* qsq, const float* qscl, int nq_launch, int blocks, hipStream_t st,
                          const BatchArgs* f) {
     const bool b = a.bias != nullptr;
-    if (a.metric == HDB_DOT) return b ? launch_one<E, MF, QT, D, R, RS, MODE, 0, true>(a, q16, nullptr, qsq, qscl, nq_launch, blocks, st, f)
-                                      : launch_one<E, MF, QT, D, R, RS, MODE, 0, false>(a, q16, nullptr, qsq, qscl, nq_launch, blocks, st, f);
-    if (a.metric == HDB_COSINE) return b ? launch_one<E, MF, QT, D, R, RS, MODE, 1, true>(a, q16, a.inv_norm, qsq, qscl, nq_launch, blocks, st, f)
-                                         : launch_one<E, MF, QT, D, R, RS, MODE, 1, false>(a, q16, a.inv_norm, qsq, qscl, nq_launch, blocks, st, f);
-    if (a.metric == HDB_EUCLIDEAN) return b ? launch_one<E, MF, QT, D, R, RS, MODE, 2, true>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st, f)
-                                            : launch_one<E, MF, QT, D, R, RS, MODE, 2, false>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st, f);
+    if (a.metric == HDB_DOT) return b ? launch_one<E, MF, QT, D, R, RS, MODE, 0, true, KP>(a, q16, nullptr, qsq, qscl, nq_launch, blocks, st, f)
+                                      : launch_one<E, MF, QT, D, R, RS, MODE, 0, false, KP>(a, q16, nullptr, qsq, qscl, nq_launch, blocks, st, f);
+    if (a.metric == HDB_COSINE) return b ? launch_one<E, MF, QT, D, R, RS, MODE, 1, true, KP>(a, q16, a.inv_norm, qsq, qscl, nq_launch, blocks, st, f)
+                                         : launch_one<E, MF, QT, D, R, RS, MODE, 1, false, KP>(a, q16, a.inv_norm, qsq, qscl, nq_launch, blocks, st, f);
+    if (a.metric == HDB_EUCLIDEAN) return b ? launch_one<E, MF, QT, D, R, RS, MODE, 2, true, KP>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st, f)
+                                            : launch_one<E, MF, QT, D, R, RS, MODE, 2, false, KP>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st, f);
     return (int)hipErrorNotSupported;
 }
 
 // mode 2 (the whole call in one launch) takes BatchArgs; q16 / qsq / qscl are unused there (the kernel prepares the queries)
-template <typename E, int MF, int QT, int D, int R, int RS = 1>
+template <typename E, int MF, int QT, int D, int R, int RS = 1, int KP = 1>
 static int launch_mode(const ScanArgs& a, int mode, const void* q16, const float* sqnorm, const float* qsq, const float* qscl, int nq_launch, int blocks, hipStream_t st,
                        const BatchArgs* f = nullptr) {
-    if (mode == 0) return launch_metric<E, MF, QT, D, R, RS, 0>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st, nullptr);
-    if (mode == 2) return launch_metric<E, MF, QT, D, R, RS, 2>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st, f);
-    return launch_metric<E, MF, QT, D, R, RS, 1>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st, nullptr);
+    if (mode == 0) return launch_metric<E, MF, QT, D, R, RS, 0, KP>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st, nullptr);
+    if (mode == 2) return launch_metric<E, MF, QT, D, R, RS, 2, KP>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st, f);
+    return launch_metric<E, MF, QT, D, R, RS, 1, KP>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st, nullptr);
 }
 

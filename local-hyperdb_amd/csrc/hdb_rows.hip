@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256) void hdb_gather_rows_kernel(const char* __rest
             const float ss = sq_in[r];
             inv_out[j] = inv_in[r]; sq_out[j] = ss;
             if (ss != ss) atomicOr(nan_flag, 1);           // the NaN flag of the compacted matrix (ranking_algorithm.py:150)
+            else if (ss - ss != 0.f) atomicOr(nan_flag, 2); // ... and its "infinite sum of squares" flag (hdb_rownorm_kernel)
         }
     }
 }

@@ -295,6 +295,7 @@ __global__ __launch_bounds__(256) void hdb_rownorm_kernel(const T* V, int64_t n,
         if ((l16 & 3) == 0 && row < n) {
             const float ss = (float)mine;
             if (ss != ss) atomicOr(nan_flag, 1);
+            else if (ss - ss != 0.f) atomicOr(nan_flag, 2);      // an infinite sum: infinite or huge elements (no bf16-part arithmetic on this matrix)
             sqnorm[row] = ss;
             inv_norm[row] = (mine == Acc(0)) ? 1.0f : (float)(Acc(1) / sqrt(mine));
         }
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(64) void hdb_qprep_kernel(const Acc* Q, int nq, int
         const float ss = (float)s;
         qsq[q] = ss;
         qinv[q] = (s == Acc(0)) ? 1.0f : (float)(Acc(1) / sqrt(s));
-        qnan[q] = (ss != ss) ? 1 : 0;
+        qnan[q] = (ss != ss) ? 1 : (ss - ss != 0.f) ? 2 : 0;       // 2 = an infinite element: hdb_finalize_kernel's inf_status
     }
 }
 

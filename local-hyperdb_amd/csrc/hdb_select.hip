@@ -264,12 +264,12 @@ __global__ __launch_bounds__(1024) void hdb_ties_seq_kernel(const float* scores,
 __global__ __launch_bounds__(1024) void hdb_finalize_kernel(const unsigned long long* cand, const uint32_t* cnt,
                                                             uint32_t cap, uint32_t k, uint32_t kk /* min(k, n) */,
                                                             int64_t row_base, int64_t* idx_out, float* score_out,
-                                                            int32_t* status, const int* qnan) {
+                                                            int32_t* status, const int* qnan, int inf_status) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long buf[];
     const int q = blockIdx.x;
     // (round 4: the register-resident flavour where the list fits 16 entries per thread and k <= 256, else the general body)
     hdb_finalize_fast(buf, cand + (int64_t)q * cap, cnt[q * HDB_CNT_STRIDE], q, cap, k, kk, row_base, idx_out, score_out, status,
-                      qnan ? qnan[q] : 0, 0);
+                      qnan ? (qnan[q] & 1) : 0, (qnan && (qnan[q] & 2)) ? inf_status : 0);       // (qnan: 1 = the query holds a NaN, 2 = an infinity)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -362,7 +362,7 @@ extern "C" int hdb_launch_collect(const float* scores, int64_t n, int64_t ld, in
 // status[q] = HDB_Q_NAN if the query held a NaN, else 0 (the full-sort path has no finalize kernel to write it)
 __global__ void hdb_status_nan_kernel(const int* qnan, int nq, int32_t* status) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nq) status[i] = qnan[i] ? HDB_Q_NAN : 0;
+    if (i < nq) status[i] = (qnan[i] & 1) ? HDB_Q_NAN : 0;
 }
 extern "C" int hdb_launch_status_nan(const int* qnan, int nq, int32_t* status, void* stream) {
     hipLaunchKernelGGL(hdb_status_nan_kernel, dim3((nq + 255) / 256), dim3(256), 0, (hipStream_t)stream, qnan, nq, status);
@@ -370,14 +370,14 @@ extern "C" int hdb_launch_status_nan(const int* qnan, int nq, int32_t* status, v
 }
 extern "C" int hdb_launch_finalize(const unsigned long long* cand, const uint32_t* cnt, uint32_t cap, int nq, uint32_t k,
                                    uint32_t kk, int64_t row_base, int64_t* idx_out, float* score_out, int32_t* status,
-                                   const int* qnan, int threads, void* stream) {
+                                   const int* qnan, int threads, int inf_status, void* stream) {
     const size_t lds = (size_t)cap * 16 + 2048 * 4 + 64;
     static unsigned long long attr_done = 0;
     hipError_t e = hdb_lds_attr_once(reinterpret_cast<const void*>(hdb_finalize_kernel), (int)lds, &attr_done);
     if (e != hipSuccess) return (int)e;
     if (threads != 256 && threads != 512) threads = 1024;
     hipLaunchKernelGGL(hdb_finalize_kernel, dim3(nq), dim3(threads), lds, (hipStream_t)stream, cand, cnt, cap, k, kk,
-                       row_base, idx_out, score_out, status, qnan);
+                       row_base, idx_out, score_out, status, qnan, inf_status);
     return (int)hipGetLastError();
 }
 extern "C" int hdb_launch_merge(const void* idx_base, int64_t idx_stride, const void* score_base, int64_t score_stride,
