@@ -56,6 +56,7 @@ int hdb_mfma_batch_capacity(int dtype, int d);
 int hdb_mfma_ksplit_slices(int dtype, int d);
 int hdb_mfma_anyd_pad(int dtype, int d);
 int hdb_mfma_f32_split_min_q(int d);
+int hdb_mfma_f32_split_max_q(int d);
 int hdb_l1_tile_supported(int dtype, int d);
 int hdb_launch_l1_tile(const ScanArgs* args, int dtype, int mode, int nq_launch, int max_blocks, void* stream);
 int hdb_bits_fused_supported(int metric, int nq, int W, uint32_t kk);
@@ -665,7 +666,7 @@ static int topk_impl(hdb_index* ix, const void* dev_Q, int32_t nq, int32_t k, in
     bool f32s = false;
     const int f32s_auto = hdb_mfma_f32_split_min_q(ix->d);
     const int f32s_min = f32s_auto > 0 ? (int)(ix->f32_split_min_q > 0 ? ix->f32_split_min_q : f32s_auto) : 0;       // queries of the CALL (every launch of a call multiplies the same way)
-    if (mfma && ix->dtype == HDB_F32 && ix->f32_split && f32s_min > 0 && nq >= f32s_min) { const int rc = matrix_is_finite(ix, &f32s); if (rc != HDB_OK) return rc; }
+    if (mfma && ix->dtype == HDB_F32 && ix->f32_split && f32s_min > 0 && nq >= f32s_min && nq <= hdb_mfma_f32_split_max_q(ix->d)) { const int rc = matrix_is_finite(ix, &f32s); if (rc != HDB_OK) return rc; }
     ix->st_f32s = f32s ? 1 : 0;
     // anything else the matrix-core scan takes (5-256 dot / cosine queries, 1-256 euclidean ones), k <= 128: one launch per
     // <= bcap queries does preparation, sample, thresholds, the pass and every query's final sort (hdb_mfma_kernel.h, MODE 2)

@@ -107,6 +107,7 @@ extern "C" int hdb_mfma_anyd_pad(int dtype, int d) {
 #define HDB_ANYD_DECL(name) extern "C" int name(const ScanArgs* args, int dpad, int mode, int nq_launch, const void* q, const float* sqnorm, \
                                               const float* qsq, const float* qscl, int blocks, void* stream)
 HDB_ANYD_DECL(hdb_launch_mfma_anyd_a); HDB_ANYD_DECL(hdb_launch_mfma_anyd_b); HDB_ANYD_DECL(hdb_launch_mfma_anyd_c); HDB_ANYD_DECL(hdb_launch_mfma_anyd_d);
+HDB_ANYD_DECL(hdb_launch_mfma_anyd_e); HDB_ANYD_DECL(hdb_launch_mfma_anyd_f);       // float32 rows as bf16 parts
 
 extern "C" int hdb_mfma_tile_rows(int dtype, int d) {
     const int pad = hdb_mfma_anyd_pad(dtype, d);
@@ -148,7 +149,16 @@ extern "C" int hdb_launch_mfma_scan_f32s(const ScanArgs* args, int mode, int nq_
 // flavour is the faster one (0: no such flavour; the API decides per call, ScanArgs::f32_split).  d <= 384: up to 32 queries the float32 MFMAs keep up with HBM (measured,
 // profiles/r4_f32_bf16_parts.txt); d = 512 / 768: one wave cannot hold the query fragments of a whole row, the float32 flavour
 // runs 16-row tiles on one SIMD per 16 queries (2x a pass at any batch size), the bf16-part flavour splits K over two waves.
-extern "C" int hdb_mfma_f32_split_min_q(int d) { return (d == 128 || d == 384) ? 33 : d == 256 ? 9 : (d == 512 || d == 768) ? 1 : 0; }
+// Other float32 widths ride these geometries (any multiple of 4 up to 768 as one padded slice, hdb_mfma_anyd.h; 1024 / 1536 as two
+// slices of 512 / 768, hdb_mfma_ksplit.hip) and follow the geometry's rule.
+// ... and the largest call that flavour takes (d = 1024: the paired waves hold 64 queries per launch row, so 65-128 queries read the
+// two slices twice -- 2 650 against 2 350 us at 128 queries on 1M rows, profiles/r4_f32_bf16_parts.txt)
+extern "C" int hdb_mfma_f32_split_max_q(int d) { return d == 1024 ? 64 : 1 << 30; }
+extern "C" int hdb_mfma_f32_split_min_q(int d) {
+    if (d == 1024 || d == 1536) return 1;
+    const int g = (d == 128 || d == 256 || d == 384 || d == 512 || d == 768) ? d : hdb_mfma_anyd_pad(HDB_F32, d);
+    return (g == 128 || g == 384) ? 33 : g == 256 ? 9 : (g == 512 || g == 768) ? 1 : 0;
+}
 extern "C" int hdb_launch_mfma_scan_f16_wide(const ScanArgs* args, int mode, int nq_launch, const void* q16, const float* sqnorm,
                                              const float* qsq, const float* qscl, int blocks, void* stream, const BatchArgs* f);
 
@@ -175,6 +185,8 @@ extern "C" int hdb_launch_mfma_scan(const ScanArgs* args, int dtype, int mode, i
         if (mode == 2) return (int)hipErrorNotSupported;
         if (dtype == HDB_F16) return pad <= 384 ? hdb_launch_mfma_anyd_a(args, pad, mode, nq_launch, q16, sqnorm, qsq, qscl, blocks, stream)
                                                 : hdb_launch_mfma_anyd_b(args, pad, mode, nq_launch, q16, sqnorm, qsq, qscl, blocks, stream);
+        if (a.f32_split) return pad <= 384 ? hdb_launch_mfma_anyd_e(args, pad, mode, nq_launch, q16, sqnorm, qsq, nullptr, blocks, stream)
+                                           : hdb_launch_mfma_anyd_f(args, pad, mode, nq_launch, q16, sqnorm, qsq, nullptr, blocks, stream);
         return pad <= 384 ? hdb_launch_mfma_anyd_c(args, pad, mode, nq_launch, q16, sqnorm, qsq, nullptr, blocks, stream)
                           : hdb_launch_mfma_anyd_d(args, pad, mode, nq_launch, q16, sqnorm, qsq, nullptr, blocks, stream);
     }

@@ -11,16 +11,16 @@
 #pragma once
 #include "hdb_mfma_kernel.h"
 
-template <typename E, int D, int R>
+template <typename E, int D, int R, int KP = 1>
 static int launch_anyd(const ScanArgs& a, int mode, const void* q, const float* sqnorm, const float* qsq, const float* qscl, int nq_launch, int blocks, hipStream_t st) {
     const bool b = a.bias != nullptr;
 #define HDB_AD_CASE(MODE_)                                                                                                                        \
-    if (a.metric == HDB_DOT) return b ? launch_kslice_one<E, D, R, MODE_, 0, true>(a, q, nullptr, qsq, qscl, nq_launch, blocks, st)                \
-                                      : launch_kslice_one<E, D, R, MODE_, 0, false>(a, q, nullptr, qsq, qscl, nq_launch, blocks, st);              \
-    if (a.metric == HDB_COSINE) return b ? launch_kslice_one<E, D, R, MODE_, 1, true>(a, q, a.inv_norm, qsq, qscl, nq_launch, blocks, st)          \
-                                         : launch_kslice_one<E, D, R, MODE_, 1, false>(a, q, a.inv_norm, qsq, qscl, nq_launch, blocks, st);        \
-    if (a.metric == HDB_EUCLIDEAN) return b ? launch_kslice_one<E, D, R, MODE_, 2, true>(a, q, sqnorm, qsq, qscl, nq_launch, blocks, st)           \
-                                            : launch_kslice_one<E, D, R, MODE_, 2, false>(a, q, sqnorm, qsq, qscl, nq_launch, blocks, st);
+    if (a.metric == HDB_DOT) return b ? launch_kslice_one<E, D, R, MODE_, 0, true, KP>(a, q, nullptr, qsq, qscl, nq_launch, blocks, st)                \
+                                      : launch_kslice_one<E, D, R, MODE_, 0, false, KP>(a, q, nullptr, qsq, qscl, nq_launch, blocks, st);              \
+    if (a.metric == HDB_COSINE) return b ? launch_kslice_one<E, D, R, MODE_, 1, true, KP>(a, q, a.inv_norm, qsq, qscl, nq_launch, blocks, st)          \
+                                         : launch_kslice_one<E, D, R, MODE_, 1, false, KP>(a, q, a.inv_norm, qsq, qscl, nq_launch, blocks, st);        \
+    if (a.metric == HDB_EUCLIDEAN) return b ? launch_kslice_one<E, D, R, MODE_, 2, true, KP>(a, q, sqnorm, qsq, qscl, nq_launch, blocks, st)           \
+                                            : launch_kslice_one<E, D, R, MODE_, 2, false, KP>(a, q, sqnorm, qsq, qscl, nq_launch, blocks, st);
     if (mode == 0) { HDB_AD_CASE(0) } else if (mode == 1) { HDB_AD_CASE(1) }
 #undef HDB_AD_CASE
     return (int)hipErrorNotSupported;

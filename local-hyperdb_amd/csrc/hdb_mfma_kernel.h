@@ -288,7 +288,7 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
     constexpr bool CONV = Shape::CONV;          // float32 tiles are turned into bf16 parts in place before they are multiplied
     static_assert(CPR % CPS == 0 && (RPF == 1 || MF == 16), "k-steps");
     constexpr int KS = CPR / CPS / KP;          // k-steps of this wave (one fragment read each)
-    static_assert(KP == 1 || (KP == 2 && Shape::CONV && NW == 8 && RS == 1 && QT == 1 && R == MF && (CPR / CPS) % 2 == 0 && (KS * CPS * 16) % 256 == 0 && MODE != 3), "K parts");
+    static_assert(KP == 1 || (KP == 2 && Shape::CONV && NW == 8 && RS == 1 && QT == 1 && R == MF && (CPR / CPS) % 2 == 0 && (KS * CPS * 16) % 256 == 0), "K parts");
     // RS > 1 ("row split"): RS consecutive waves share one query group and take every RS-th row tile of the stage each,
     // so that few queries still spread their MFMAs over all four SIMDs (fp32 MFMAs bind long before HBM does)
     constexpr int RT = R / MF / RS;             // MFMA row tiles per stage and wave
@@ -1301,28 +1301,28 @@ static int launch_one(const ScanArgs& a, const void* q16, const float* aux0, con
 }
 
 // One K slice of a wide-row scan (hdb_mfma_ksplit.hip): mode 3 = raw partial sums out, 0 / 1 = the last slice with the metric's epilogue
-template <typename E, int D, int R, int MODE, int METRIC, bool HAS_BIAS>
+template <typename E, int D, int R, int MODE, int METRIC, bool HAS_BIAS, int KP = 1>
 static int launch_kslice_one(const ScanArgs& a, const void* q16, const float* aux0, const float* qsq, const float* qscl, int nq_launch, int blocks, hipStream_t st) {
-    auto kern = hdb_mfma_kernel<E, 16, 1, D, R, 1, MODE, METRIC, HAS_BIAS, 8, true>;
+    auto kern = hdb_mfma_kernel<E, 16, 1, D, R, 1, MODE, METRIC, HAS_BIAS, 8, true, KP>;
     const size_t lds = mfma_lds_bytes(R * D * (int)sizeof(E));
     static unsigned long long attr_done = 0;
     hipError_t e = hdb_lds_attr_once(reinterpret_cast<const void*>(kern), (int)lds, &attr_done);
     if (e != hipSuccess) return (int)e;
-    const dim3 grid(blocks, (nq_launch + 8 * 16 - 1) / (8 * 16));
+    const dim3 grid(blocks, (nq_launch + 8 / KP * 16 - 1) / (8 / KP * 16));
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, a, (const E*)q16, aux0, qsq, qscl, a.q0 + nq_launch, BatchArgs());
     return (int)hipGetLastError();
 }
-template <typename E, int D, int R>
+template <typename E, int D, int R, int KP = 1>
 static int launch_kslice(const ScanArgs& a, int mode, const void* q16, const float* sqnorm, const float* qsq, const float* qscl, int nq_launch, int blocks, hipStream_t st) {
-    if (mode == 3) return launch_kslice_one<E, D, R, 3, 0, false>(a, q16, nullptr, qsq, qscl, nq_launch, blocks, st);
+    if (mode == 3) return launch_kslice_one<E, D, R, 3, 0, false, KP>(a, q16, nullptr, qsq, qscl, nq_launch, blocks, st);
     const bool b = a.bias != nullptr;
 #define HDB_KS_CASE(MODE_)                                                                                                                        \
-    if (a.metric == HDB_DOT) return b ? launch_kslice_one<E, D, R, MODE_, 0, true>(a, q16, nullptr, qsq, qscl, nq_launch, blocks, st)              \
-                                      : launch_kslice_one<E, D, R, MODE_, 0, false>(a, q16, nullptr, qsq, qscl, nq_launch, blocks, st);            \
-    if (a.metric == HDB_COSINE) return b ? launch_kslice_one<E, D, R, MODE_, 1, true>(a, q16, a.inv_norm, qsq, qscl, nq_launch, blocks, st)        \
-                                         : launch_kslice_one<E, D, R, MODE_, 1, false>(a, q16, a.inv_norm, qsq, qscl, nq_launch, blocks, st);      \
-    if (a.metric == HDB_EUCLIDEAN) return b ? launch_kslice_one<E, D, R, MODE_, 2, true>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st)         \
-                                            : launch_kslice_one<E, D, R, MODE_, 2, false>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
+    if (a.metric == HDB_DOT) return b ? launch_kslice_one<E, D, R, MODE_, 0, true, KP>(a, q16, nullptr, qsq, qscl, nq_launch, blocks, st)              \
+                                      : launch_kslice_one<E, D, R, MODE_, 0, false, KP>(a, q16, nullptr, qsq, qscl, nq_launch, blocks, st);            \
+    if (a.metric == HDB_COSINE) return b ? launch_kslice_one<E, D, R, MODE_, 1, true, KP>(a, q16, a.inv_norm, qsq, qscl, nq_launch, blocks, st)        \
+                                         : launch_kslice_one<E, D, R, MODE_, 1, false, KP>(a, q16, a.inv_norm, qsq, qscl, nq_launch, blocks, st);      \
+    if (a.metric == HDB_EUCLIDEAN) return b ? launch_kslice_one<E, D, R, MODE_, 2, true, KP>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st)         \
+                                            : launch_kslice_one<E, D, R, MODE_, 2, false, KP>(a, q16, sqnorm, qsq, qscl, nq_launch, blocks, st);
     if (mode == 0) { HDB_KS_CASE(0) } else { HDB_KS_CASE(1) }
 #undef HDB_KS_CASE
     return (int)hipErrorNotSupported;

@@ -21,6 +21,8 @@ static KsGeom ks_geom(int dtype, int d) {
     return {0, 0};
 }
 extern "C" int hdb_mfma_ksplit_slices(int dtype, int d) { return ks_geom(dtype, d).slices; }
+extern "C" int hdb_launch_mfma_kslice_f32s(const ScanArgs* a, int dslice, int mode, int nq_launch, const void* q, const float* sqnorm,
+                                           const float* qsq, int blocks, void* stream);      // hdb_mfma_ksplit_s.hip
 
 // args->ks_partial_out: [nq_launch][ks_ld] float32 scratch of the caller (MODE 0 passes may alias it with args->scores: the last
 // slice overwrites the sums with the scores, element by element, by the lane that read them)
@@ -36,7 +38,8 @@ extern "C" int hdb_launch_mfma_ksplit(const ScanArgs* args, int dtype, int mode,
         a.ks_partial_in = s == 0 ? nullptr : args->ks_partial_out;
         const int m = s + 1 < g.slices ? 3 : mode;
         int rc;
-        if (dtype == HDB_F32) rc = g.dslice == 512 ? launch_kslice<float, 512, 16>(a, m, q, sqnorm, qsq, nullptr, nq_launch, blocks, st)
+        if (dtype == HDB_F32 && args->f32_split) rc = hdb_launch_mfma_kslice_f32s(&a, g.dslice, m, nq_launch, q, sqnorm, qsq, blocks, stream);
+        else if (dtype == HDB_F32) rc = g.dslice == 512 ? launch_kslice<float, 512, 16>(a, m, q, sqnorm, qsq, nullptr, nq_launch, blocks, st)
                                                    : launch_kslice<float, 768, 16>(a, m, q, sqnorm, qsq, nullptr, nq_launch, blocks, st);
         else rc = g.dslice == 1024 ? launch_kslice<_Float16, 1024, 16>(a, m, q, sqnorm, qsq, qscl, nq_launch, blocks, st)
                                    : launch_kslice<_Float16, 1536, 16>(a, m, q, sqnorm, qsq, qscl, nq_launch, blocks, st);

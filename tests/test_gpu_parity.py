@@ -948,7 +948,10 @@ def test_fp32_mfma_batches_match_valu_and_oracle(orc, d, nq, metric, bias):
                                               (384, 128, "dot_product", True), (384, 150, "cosine_similarity", False),
                                               (384, 40, "pearson_correlation", False),
                                               (512, 5, "cosine_similarity", False), (512, 64, "euclidean_metric", True), (512, 100, "dot_product", False),
-                                              (768, 16, "cosine_similarity", False), (768, 64, "euclidean_metric", False), (768, 130, "dot_product", True)])
+                                              (768, 16, "cosine_similarity", False), (768, 64, "euclidean_metric", False), (768, 130, "dot_product", True),
+                                              # widths that ride a padded geometry (hdb_mfma_anyd.h) or two K slices (hdb_mfma_ksplit.hip)
+                                              (100, 40, "cosine_similarity", False), (300, 64, "dot_product", True), (500, 16, "cosine_similarity", False),
+                                              (700, 70, "euclidean_metric", True), (1024, 16, "cosine_similarity", False), (1536, 40, "euclidean_metric", False)])
 def test_fp32_batches_as_bf16_parts_match_the_float32_flavour_and_oracle(orc, d, nq, metric, bias):
     """float32 matrices, larger batches: the rows travel as two bf16 parts (converted in LDS, in place), the queries as three exact
     parts, five bf16 MFMAs per k-step (hdb_mfma_f32s.hip; d = 512 / 768: two waves share the k-steps of a row).  Same answer as
@@ -956,7 +959,7 @@ def test_fp32_batches_as_bf16_parts_match_the_float32_flavour_and_oracle(orc, d,
     single launch and in the multi-kernel pipeline."""
     from hyperdb._native import GpuIndex, METRIC_IDS
     rng = np.random.default_rng(d * 977 + nq)
-    n, k = 70_000 + 5, 50
+    n, k = (70_000 if d <= 768 else 30_000) + 5, 50
     V = rng.standard_normal((n, d)).astype(np.float32)
     Q = rng.standard_normal((nq, d)).astype(np.float32)
     Q[0] = V[n - 3]                                             # exact duplicate of a row in the ragged last tile
