@@ -30,10 +30,11 @@ One JSON line is printed by rank 0.  Besides the contract fields it carries
                    ranking_algorithm.py:149, hyperdb.py:1584), beside the p50 of the kernel path the headline times.
   exchange_alt  -- (--gpus N > 1) both transports of the per-query exchange are timed in the same run: `value` uses the one
                    named in config.exchange (chosen by a calibration inside the warm-up), exchange_alt reports the other.
-  extra         -- (--gpus 1, default legs c2,c5,hamming,shard,small) the other BASELINE.json configs and the supplementary
+  extra         -- (--gpus 1, default legs c2,c5,hamming,shard,f32batch,small) the other BASELINE.json configs and the supplementary
                    workloads, each with workload / kernel / kernel_us / roofline{achieved, peak, frac, algorithmic_bytes_per_launch}:
                    c2 = config 2 (N=1M fp32 cosine), c5 = config 5 (N=10M d=768 euclidean + time decay, Q=64), hamming = the
                    headline matrix through hamming_distance, shard = the per-GPU share of the headline at 8 GPUs (N=1.25M),
+                   f32batch = 64 cosine queries on a float32 2M x 384 matrix (rows multiplied as bf16 parts; + roofline_mfma),
                    small = p50 of the drop-in entry point on reference-sized matrices (1k / 10k / 100k rows, host numpy queries).
   rccl          -- (--gpus N > 1) {backend, world, devices: [(rank, host, local device, pci bus id) all-gathered from the ranks],
                    exchange, record_bytes} and `parity`: the sharded answer on a 1M-row prefix of the same matrix against rank 0's
@@ -76,8 +77,8 @@ def parse():
     ap.add_argument("--batch-steps", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=1_000_000, help="row prefix the CPU baseline is timed on (BASELINE.md section 4)")
-    ap.add_argument("--extra", default="c2,c5,hamming,shard,small",
-                    help="comma list of extra legs timed after the headline (one GPU): c2,c5,hamming,shard,small; '' = none")
+    ap.add_argument("--extra", default="c2,c5,hamming,shard,f32batch,small",
+                    help="comma list of extra legs timed after the headline (one GPU): c2,c5,hamming,shard,f32batch,small; '' = none")
     ap.add_argument("--pmc-traffic", type=float, default=None,
                     help="HBM bytes per launch of the dominant kernel from a separate rocprofv3 --pmc run")
     return ap.parse_args()
@@ -161,6 +162,8 @@ def extra_leg(name, device):
         n, d, dt, elem, q, metric, steps, bias = 10_000_000, 384, torch.float16, 2, 1, "hamming_distance", 200, False
     elif name == "shard":     # what one GPU of an 8-GPU node holds of the headline matrix (strong scaling): the call that bounds the 8-GPU QPS
         n, d, dt, elem, q, metric, steps, bias = 1_250_000, 384, torch.float16, 2, 1, "cosine_similarity", 300, False
+    elif name == "f32batch":  # the reference's default precision (hyperdb.py:51) in batches: float32 rows as bf16 parts on the matrix cores (hdb_mfma_f32s.hip)
+        n, d, dt, elem, q, metric, steps, bias = 2_000_000, 384, torch.float32, 4, 64, "cosine_similarity", 30, False
     elif name == "small":
         return small_leg(device)
     else:
@@ -204,6 +207,14 @@ def extra_leg(name, device):
            "kernel_us": kern_s * 1e6, "mfma_path": bool(ix.stat("mfma")), "single_launch": bool(fused),
            "roofline": {"bound": "hbm", "achieved": alg / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": alg / kern_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg}}
+    if name == "f32batch":     # the matrix-pipe side of the same launch: algorithmic flops (2 Q d per row) and what the pipe multiplies for them
+        parts = bool(ix.stat("f32_split"))
+        flops = 2.0 * n * q * d
+        out["bf16_parts"] = parts
+        out["roofline_mfma"] = {"bound": "mfma", "achieved": flops / kern_s / 1e12, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "frac": flops / kern_s / 1e12 / MFMA_F16_PEAK_TFLOPS, "algorithmic_flops_per_launch": flops,
+                                "products_per_flop": 5 if parts else 1,
+                                "pipe_tflops": (5 if parts else 1) * flops / kern_s / 1e12}
     ix.close()
     del V
     torch.cuda.empty_cache()
