@@ -145,10 +145,11 @@ extern "C" int hdb_launch_mfma_scan_f32(const ScanArgs* args, int mode, int nq_l
                                         const float* qsq, int blocks, void* stream, const BatchArgs* f);
 extern "C" int hdb_launch_mfma_scan_f32s(const ScanArgs* args, int mode, int nq_launch, const void* q, const float* sqnorm,
                                          const float* qsq, int blocks, void* stream, const BatchArgs* f);
-// float32 widths whose scan also exists in bf16 parts (hdb_mfma_f32s.hip) -> the number of queries of a launch from which that
-// flavour is the faster one (0: no such flavour; the API decides per call, ScanArgs::f32_split).  d <= 384: up to 32 queries the float32 MFMAs keep up with HBM (measured,
-// profiles/r4_f32_bf16_parts.txt); d = 512 / 768: one wave cannot hold the query fragments of a whole row, the float32 flavour
-// runs 16-row tiles on one SIMD per 16 queries (2x a pass at any batch size), the bf16-part flavour splits K over two waves.
+// float32 widths whose scan also exists in bf16 parts (hdb_mfma_f32s.hip) -> the number of queries of a CALL from which that
+// flavour is used (0: no such flavour; the API decides per call, ScanArgs::f32_split).  d <= 384: measured from 16 queries up, never
+// slower than the float32 MFMAs and 1.5-1.7x faster from 48 (profiles/r4_f32_bf16_parts.txt); d = 512 / 768: one wave cannot hold the
+// query fragments of a whole row, the float32 flavour runs 16-row tiles on one SIMD per 16 queries (2x a pass at any batch size), the
+// bf16-part flavour splits K over two waves.
 // Other float32 widths ride these geometries (any multiple of 4 up to 768 as one padded slice, hdb_mfma_anyd.h; 1024 / 1536 as two
 // slices of 512 / 768, hdb_mfma_ksplit.hip) and follow the geometry's rule.
 // ... and the largest call that flavour takes (d = 1024: the paired waves hold 64 queries per launch row, so 65-128 queries read the
@@ -157,7 +158,7 @@ extern "C" int hdb_mfma_f32_split_max_q(int d) { return d == 1024 ? 64 : 1 << 30
 extern "C" int hdb_mfma_f32_split_min_q(int d) {
     if (d == 1024 || d == 1536) return 1;
     const int g = (d == 128 || d == 256 || d == 384 || d == 512 || d == 768) ? d : hdb_mfma_anyd_pad(HDB_F32, d);
-    return (g == 128 || g == 384) ? 33 : g == 256 ? 9 : (g == 512 || g == 768) ? 1 : 0;
+    return (g == 128 || g == 256 || g == 384) ? 9 : (g == 512 || g == 768) ? 1 : 0;
 }
 extern "C" int hdb_launch_mfma_scan_f16_wide(const ScanArgs* args, int mode, int nq_launch, const void* q16, const float* sqnorm,
                                              const float* qsq, const float* qscl, int blocks, void* stream, const BatchArgs* f);

@@ -12,7 +12,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define HDB_MFMA_CB 1024            // LDS candidate list entries per workgroup
 #define HDB_MFMA_SEG (HDB_MFMA_CB / 8)   // ... per wave
 // Measurement builds only (tools/knockout_q256.py; the product is built with 0): 1 = survivors are never appended,
-// 2 = no LDS-DMA once the ring is primed (stale but random tiles), 4 = no per-tile barrier, 8 = half of the fragment reads (row tiles 1 and 3 reuse 0 and 2).  Results are wrong by design.
+// 2 = no LDS-DMA once the ring is primed (stale but random tiles), 4 = no per-tile barrier, 8 = half of the fragment reads (row tiles 1 and 3 reuse 0 and 2),
+// 16 = no in-place conversion of float32 tiles (hdb_f32s), 32 = one of the five part products only.  Results are wrong by design.
 #ifndef HDB_MFMA_KNOCKOUT
 #define HDB_MFMA_KNOCKOUT 0
 #endif
@@ -36,6 +37,19 @@ static __device__ unsigned long long hdb_batch_stamps[16 * 1024];
 #define HDB_BSTAMP(slot) do { if (ONE && tid == 0 && blockIdx.x < 1024) hdb_batch_stamps[16 * blockIdx.x + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define HDB_BSTAMP(slot) do { } while (0)
+#endif
+// Diagnostic build only (tools/round_sections.py; product: 0): every wave adds up the shader clocks (s_memtime) it spends in the
+// sections of a round -- [0] waiting at the round's barrier, [1] staging, [2] multiplying (+ handing partial sums over), [3] waiting
+// at the K-part barrier, [4] epilogue, [5] waiting for / converting the next tile, [6] rounds -- and stores them per workgroup and
+// wave into a buffer of its own at the end of the launch.
+#ifndef HDB_ROUND_PROF
+#define HDB_ROUND_PROF 0
+#endif
+#if HDB_ROUND_PROF
+static __device__ unsigned long long hdb_round_prof[256 * 8 * 8];
+#define HDB_RP(slot) do { const unsigned long long rp_now = __builtin_amdgcn_s_memtime(); rp_acc[slot] += rp_now - rp_t; rp_t = rp_now; } while (0)
+#else
+#define HDB_RP(slot) do { } while (0)
 #endif
 #if HDB_MFMA_CLOCK
 #define HDB_CLOCK_WGS 1024
@@ -230,10 +244,12 @@ template <> struct MfmaShape<16, hdb_f32s> {
     static constexpr bool CONV = true;
     __device__ static __forceinline__ Acc mma(const Vec& a, const HdbParts3& b, Acc c) {
 #define HDB_BF(x) __builtin_bit_cast(hdb_bf16x8, x)
+        if (!(HDB_MFMA_KNOCKOUT & 32)) {
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HDB_BF(a.hi), HDB_BF(b.p1), c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HDB_BF(a.lo), HDB_BF(b.p2), c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HDB_BF(a.hi), HDB_BF(b.p0), c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(HDB_BF(a.lo), HDB_BF(b.p1), c, 0, 0, 0);
+        }
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(HDB_BF(a.lo), HDB_BF(b.p0), c, 0, 0, 0);
 #undef HDB_BF
     }
@@ -513,9 +529,11 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
         char* sdst = smem + st * STAGE;
         const int64_t pitch = KSL ? a.ks_pitch : (int64_t)ROWB;
         const char* tile_base = Vb + row0 * pitch + (KSL ? a.ks_off : 0);
+        // (float32 tiles that become bf16 parts: EVERY wave stages an eighth of the tile -- pieces w, w + 8, ... -- and converts it, see
+        //  convert_own; otherwise waves 4-7 stage a quarter each)
 #pragma unroll
-        for (int j = 0; j < PPL; ++j) {
-            const int pc = (w & 3) + 4 * j;
+        for (int j = 0; j < (CONV ? PPL / 2 : PPL); ++j) {
+            const int pc = CONV ? w + 8 * j : (w & 3) + 4 * j;
             const int slot = pc * 64 + lane;
             const int r = slot / CPR, cpos = slot - r * CPR;
             const int rr = r <= (int)last ? r : (int)last;
@@ -635,37 +653,43 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
     };
     auto issue = [&](int64_t row0, int st) {
         if ((HDB_MFMA_KNOCKOUT & 2) && gp > 3) return;           // knock-out: the ring keeps its first three tiles
-        if (grpB) { issue_rows(row0, st); issue_aux(row0, st); }
+        if (grpB || CONV) issue_rows(row0, st);
+        if (grpB) issue_aux(row0, st);
     };
-    // CONV (float32 rows as bf16 parts, MfmaShape<16, hdb_f32s>): a staging wave turns the pieces IT staged into [a0 x 8][a1 x 8]
-    // groups, in place, as soon as its own vmcnt says they have landed -- one tile ahead of the multiplying waves, so the round's
-    // one barrier still separates writer and readers.  32-byte slot sl of a stage (row r = sl / (CPR/2)) holds the chunks 2g and
+    // CONV (float32 rows as bf16 parts, MfmaShape<16, hdb_f32s>): every wave stages an eighth of each tile and turns the pieces IT
+    // staged into [a0 x 8][a1 x 8] groups, in place, as soon as its own vmcnt says they have landed -- one tile ahead of the
+    // multiplication, so the round's one barrier still separates writer and readers.  (First version: waves 4-7 staged and converted
+    // a quarter each -- their round was stage 1 090 + convert 2 730 clocks against 2 270 of multiplying in waves 0-3, which waited
+    // 1 400 at the barrier: profiles/r4_f32_round_sections.txt.)  32-byte slot sl of a stage (row r = sl / (CPR/2)) holds the chunks 2g and
     // 2g+1 of its row, the odd one first where the row's swizzle (r & 15) is odd.  Two 1-KiB pieces = 64 slots per step.
     auto convert_own = [&](int st) __attribute__((always_inline)) {
-        if constexpr (CONV) {
+        if constexpr (CONV && !(HDB_MFMA_KNOCKOUT & 16)) {      // (knock-out 16: the tiles stay float32 bit patterns -- timing only)
             static_assert(NW == 8 && PPL % 4 == 0, "conversion shares");
             const unsigned int cbase = (unsigned int)(uintptr_t)HDB_LDS_PTR(smem) + (unsigned int)(st * STAGE);
+            constexpr int NS = PPL / 4;                         // 32-byte slots per lane: two 1-KiB pieces = 64 slots per step
+            unsigned int alo[NS];
+            f32x4 clo[NS], chi[NS];
 #pragma unroll
-            for (int j = 0; j < PPL; j += 4) {                  // four pieces = two slots per lane and step: four reads in flight
-                unsigned int alo[2];
-                f32x4 clo[2], chi[2];
+            for (int u = 0; u < NS; ++u) {
+                const unsigned int pc = (unsigned int)(w + 8 * (2 * u + (lane >> 5)));
+                const unsigned int sl = pc * 32u + (unsigned int)(lane & 31);
+                // (the first k-chunk of every slot first: 16 consecutive lanes touch half of the LDS banks twice.  Alternating the order every
+                //  8 slots -- with the query parts and the MFMA operands of those k-groups swapped to match -- was built and measured: no
+                //  change, the conversion waits for its turn at the LDS behind the fragment reads, not for bandwidth.)
+                const unsigned int odd = (sl / (CPR / 2)) & 1u;
+                alo[u] = cbase + sl * 32u + odd * 16u;
+                asm volatile("ds_read_b128 %0, %1" : "=v"(clo[u]) : "v"(alo[u]) : "memory");
+                asm volatile("ds_read_b128 %0, %1" : "=v"(chi[u]) : "v"(alo[u] ^ 16u) : "memory");
+            }
+            static_assert(NS == 2 || NS == 3, "conversion shares");        // (the outputs of all the reads hang on this wait: nothing of them moves above it)
+            if constexpr (NS == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(clo[0]), "+v"(chi[0]), "+v"(clo[1]), "+v"(chi[1]) :: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(clo[0]), "+v"(chi[0]), "+v"(clo[1]), "+v"(chi[1]), "+v"(clo[NS - 1]), "+v"(chi[NS - 1]) :: "memory");
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const unsigned int pc = (unsigned int)((w & 3) + 4 * (j + 2 * u + (lane >> 5)));
-                    const unsigned int sl = pc * 32u + (unsigned int)(lane & 31);
-                    const unsigned int odd = (sl / (CPR / 2)) & 1u;
-                    alo[u] = cbase + sl * 32u + odd * 16u;
-                }
-                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(clo[0]), "=&v"(chi[0]), "=&v"(clo[1]), "=&v"(chi[1])
-                             : "v"(alo[0]), "v"(alo[0] ^ 16u), "v"(alo[1]), "v"(alo[1] ^ 16u) : "memory");
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    u32x4 a0, a1;
-                    hdb_round2(clo[u], chi[u], a0, a1);
-                    asm volatile("ds_write_b128 %0, %1" :: "v"(alo[u]), "v"(a0) : "memory");
-                    asm volatile("ds_write_b128 %0, %1" :: "v"(alo[u] ^ 16u), "v"(a1) : "memory");
-                }
+            for (int u = 0; u < NS; ++u) {
+                u32x4 a0, a1;
+                hdb_round2(clo[u], chi[u], a0, a1);
+                asm volatile("ds_write_b128 %0, %1" :: "v"(alo[u]), "v"(a0) : "memory");
+                asm volatile("ds_write_b128 %0, %1" :: "v"(alo[u] ^ 16u), "v"(a1) : "memory");
             }
         }
     };
@@ -683,8 +707,8 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
         if (vA) issue(rA, st_cur);
         if (vB) issue(rB, st_cur == 2 ? 0 : st_cur + 1);
         if constexpr (CONV) {
-            if (grpB && vA) {                                // the first tile of the pass: converted before the first barrier
-                if (vB) hdb_wait_vmcnt<PPL + NAUX>(); else hdb_wait_vmcnt<0>();
+            if (vA) {                                        // the first tile of the pass: converted before the first barrier
+                if (!vB) hdb_wait_vmcnt<0>(); else if (grpB) hdb_wait_vmcnt<PPL / 2 + NAUX>(); else hdb_wait_vmcnt<PPL / 2>();
                 convert_own(st_cur);
             }
         }
@@ -792,6 +816,9 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
 #endif
     Acc acc[QT][RT];
     int64_t row0_prev = 0;
+#if HDB_ROUND_PROF
+    unsigned long long rp_acc[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+#endif
     // One pass over the current tile sequence.  ph = 0: MODE 2's sample pass (the epilogue feeds sample_update), otherwise the
     // pass the MODE names.
     auto run_pass = [&](auto ph) __attribute__((always_inline)) {
@@ -799,14 +826,43 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
     auto epi = [&](const Acc (&tv)[QT][RT], int64_t row0) __attribute__((always_inline)) {
         if constexpr (SAMPLE) sample_update(tv); else filter(tv, row0);
     };
+#if HDB_ROUND_PROF
+    unsigned long long rp_t = __builtin_amdgcn_s_memtime();
+#endif
     for (int64_t i = 0; vA; ++i) {
         if (!vB) hdb_wait_vmcnt<0>();
+        else if (CONV) { if (grpB) hdb_wait_vmcnt<PPL / 2 + NAUX>(); else hdb_wait_vmcnt<PPL / 2>(); }
         else if (grpB) hdb_wait_vmcnt<PPL + NAUX>();         // all but the newest tile's pieces are in
         if (!(HDB_MFMA_KNOCKOUT & 4)) hdb_lds_barrier();     // tile i is in LDS; everyone is done with tile i-1; dq hand-over
+        HDB_RP(0);
         // Stage the whole next-but-one tile right after the barrier, into the buffer tile i-1 used.
         const int st_next2 = st_cur == 0 ? 2 : st_cur - 1;
         if (vB) gen(tC, rC, vC); else vC = false;
-        if (vC) issue(rC, st_next2);
+        // CONV, one barrier per round: the two waves of a SIMD take the round's two halves in opposite order -- waves 4-7 stage and
+        // convert first and multiply afterwards, waves 0-3 multiply first -- so that one wave's MFMAs run under the other's VALU / LDS
+        // work instead of both queueing for the same unit (profiles/r4_f32_round_sections.txt)
+        constexpr bool SWAP = CONV && KP == 1;
+        auto stage_and_convert = [&]() __attribute__((always_inline)) {
+            if (vC) issue(rC, st_next2);
+            if constexpr (CONV) {
+                if (vB) {                                    // tile i+1 (issued a round ago): this wave's pieces are in -> bf16 parts
+#if HDB_ROUND_PROF
+                    { const unsigned long long rp_now = __builtin_amdgcn_s_memtime(); rp_acc[grpB ? 1 : 5] += rp_now - rp_t; rp_t = rp_now; }      // [1] / [5]: staging alone
+#endif
+                    if (!vC) hdb_wait_vmcnt<0>(); else if (grpB) hdb_wait_vmcnt<PPL / 2 + NAUX>(); else hdb_wait_vmcnt<PPL / 2>();
+#if HDB_ROUND_PROF
+                    { const unsigned long long rp_now = __builtin_amdgcn_s_memtime(); rp_acc[7] += rp_now - rp_t; rp_t = rp_now; }                    // [7]: waiting for the pieces of tile i+1
+#endif
+                    convert_own(st_cur == 2 ? 0 : st_cur + 1);
+#if HDB_ROUND_PROF
+                    { const unsigned long long rp_now = __builtin_amdgcn_s_memtime(); rp_acc[grpB ? 5 : 1] += rp_now - rp_t; rp_t = rp_now; }      // conversion alone (booked on the other slot)
+#endif
+                }
+            }
+        };
+        if constexpr (SWAP) { if (grpB) stage_and_convert(); }
+        else if (vC) issue(rC, st_next2);
+        HDB_RP(1);
 
         if (wave_active) {
             const int64_t row0 = rA;
@@ -906,7 +962,9 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
                 if (kp_upper) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3\n\tds_write_b128 %0, %1" :: "v"(seg_cb + (unsigned int)lane * 16u), "v"(acc[0][0]) : "memory");
             }
         }
+        HDB_RP(2);
         if constexpr (KP == 2) hdb_lds_barrier();
+        HDB_RP(3);
         if (wave_active && !kp_upper) {
             const int64_t row0 = rA;
             if constexpr (KP == 2) {
@@ -1000,12 +1058,18 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
                 else row0_prev = row0;
             }
         }
-        if constexpr (CONV) {
-            if (grpB && vB) {                                // tile i+1 (issued a round ago): this wave's pieces are in -> bf16 parts
-                if (vC) hdb_wait_vmcnt<PPL + NAUX>(); else hdb_wait_vmcnt<0>();
+        HDB_RP(4);
+        if constexpr (SWAP) { if (!grpB) stage_and_convert(); }
+        else if constexpr (CONV) {
+            if (vB) {                                        // tile i+1 (issued a round ago): this wave's pieces are in -> bf16 parts
+                if (!vC) hdb_wait_vmcnt<0>(); else if (grpB) hdb_wait_vmcnt<PPL / 2 + NAUX>(); else hdb_wait_vmcnt<PPL / 2>();
                 convert_own(st_cur == 2 ? 0 : st_cur + 1);
             }
         }
+        HDB_RP(5);
+#if HDB_ROUND_PROF
+        rp_acc[6] += 1ull;
+#endif
         st_cur = st_cur == 2 ? 0 : st_cur + 1;
         tA = tB; rA = rB; vA = vB; tB = tC; rB = rC; vB = vC;
     }
@@ -1021,6 +1085,12 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
                 unsigned long long* o = hdb_clock_buf + 4 * blockIdx.x;
                 o[0] = clk_c0; o[1] = clk_c1; o[2] = clk_r0; o[3] = clk_r1;
             }
+        }
+#endif
+#if HDB_ROUND_PROF
+        if (lane == 0 && blockIdx.x < 256 && blockIdx.y == 0 && FILT) {
+#pragma unroll
+            for (int kx = 0; kx < 8; ++kx) hdb_round_prof[((int)blockIdx.x * 8 + w) * 8 + kx] = rp_acc[kx];
         }
 #endif
         if (MODE == 1) flush();
@@ -1181,6 +1251,12 @@ __global__ __launch_bounds__(NW * 64) void hdb_mfma_kernel(ScanArgs a, const E* 
         }
 #endif
         HDB_BSTAMP(6);
+#if HDB_ROUND_PROF
+        if (lane == 0 && blockIdx.x < 256 && blockIdx.y == 0 && FILT) {
+#pragma unroll
+            for (int kx = 0; kx < 8; ++kx) hdb_round_prof[((int)blockIdx.x * 8 + w) * 8 + kx] = rp_acc[kx];
+        }
+#endif
         flush();
         // ---- finish: drain, release, arrive; wait for everybody; owners sort their queries
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
