@@ -160,8 +160,8 @@ __global__ __launch_bounds__(512) void hdb_l1_tile_kernel(ScanArgs a, int nq_end
                     const half2v ones = {(_Float16)1.0f, (_Float16)1.0f};
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        // (one cast of the whole chunk into a struct of four dwords: element-wise reads of the asm-produced vector, raw[u][dw],
-                        //  all come out as dword 0 -- the same quirk the float32 flavour works around with its half8 cast)
+                        // (one cast of the whole chunk into a struct of four dwords: __builtin_bit_cast of an ELEMENT of an ext_vector, raw[u][dw],
+                        //  reads element 0 whatever the index (hipcc 7.2) -- the float32 flavour casts the whole half8 for the same reason)
                         const uint4 r4 = __builtin_bit_cast(uint4, raw[u]);
                         const unsigned int rd[4] = {r4.x, r4.y, r4.z, r4.w};
 #pragma unroll
